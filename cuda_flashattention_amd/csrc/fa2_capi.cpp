@@ -1,0 +1,198 @@
+// fa2_capi.cpp -- the C ABI of libfa2_mi355x.so (include/fa2_mi355x.h): argument checking,
+// status codes and dispatch.  No kernels here and no framework types; the host wrappers of
+// the reference (flash_attention_kernel.cu:300-343, flash_attention_backward_kernel.cu:249-299)
+// become these functions.
+#include "../../include/fa2_mi355x.h"
+#include "fa2_launch.h"
+
+#include <hip/hip_runtime.h>
+#include <mutex>
+
+namespace {
+
+inline int hip_status(hipError_t e) { return e == hipSuccess ? FA2_OK : FA2_ERR_HIP_BASE - (int)e; }
+
+inline int check_common(int B, int H, int N, int d, float scale)
+{
+    if (B <= 0 || H <= 0 || N <= 0 || d <= 0) return FA2_ERR_INVALID_SHAPE;
+    if (!(scale > 0.0f)) return FA2_ERR_INVALID_SHAPE;
+    if ((long long)B * H > 0x7fffffffLL / 64) return FA2_ERR_INVALID_SHAPE;
+    return FA2_OK;
+}
+
+inline int check_dim(int d, int dtype)
+{
+    if (dtype == FA2_DTYPE_BF16) return (d == 64 || d == 128) ? FA2_OK : FA2_ERR_UNSUPPORTED_HEAD_DIM;
+    if (dtype == FA2_DTYPE_F32) return (d >= 1 && d <= 128) ? FA2_OK : FA2_ERR_UNSUPPORTED_HEAD_DIM;
+    return FA2_ERR_UNSUPPORTED_DTYPE;
+}
+
+// Grow-only per-device scratch for the reference-signature backward, which has no workspace
+// argument (the reference cudaMemsets inside its wrapper too, :282-283).
+struct ScratchCache {
+    std::mutex mu;
+    void* ptr[64] = {};
+    size_t cap[64] = {};
+    int get(size_t bytes, void** out)
+    {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return hip_status(e);
+        if (dev < 0 || dev >= 64) return FA2_ERR_UNSUPPORTED;
+        std::lock_guard<std::mutex> g(mu);
+        if (cap[dev] < bytes) {
+            if (ptr[dev]) {
+                e = hipDeviceSynchronize();      // nothing may still be using the old block
+                if (e != hipSuccess) return hip_status(e);
+                (void)hipFree(ptr[dev]);
+                ptr[dev] = nullptr; cap[dev] = 0;
+            }
+            e = hipMalloc(&ptr[dev], bytes);
+            if (e != hipSuccess) return hip_status(e);
+            cap[dev] = bytes;
+        }
+        *out = ptr[dev];
+        return FA2_OK;
+    }
+} g_scratch;
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" {
+
+const char* fa2_version(void) { return "fa2_mi355x 0.1 (gfx950)"; }
+
+const char* fa2_status_string(int s)
+{
+    switch (s) {
+    case FA2_OK: return "ok";
+    case FA2_ERR_NULL_POINTER: return "null pointer";
+    case FA2_ERR_INVALID_SHAPE: return "invalid shape or scale";
+    case FA2_ERR_UNSUPPORTED_HEAD_DIM: return "unsupported head_dim";
+    case FA2_ERR_UNSUPPORTED_DTYPE: return "unsupported dtype";
+    case FA2_ERR_WORKSPACE: return "workspace missing or too small";
+    case FA2_ERR_UNSUPPORTED: return "unsupported combination";
+    default: break;
+    }
+    if (s <= FA2_ERR_RCCL_BASE) return "RCCL error (code = -(status) - 2000)";
+    if (s <= FA2_ERR_HIP_BASE) return hipGetErrorString((hipError_t)(FA2_ERR_HIP_BASE - s));
+    return "unknown status";
+}
+
+int fa2_forward(const void* Q, const void* K, const void* V, void* O, float* L,
+                int B, int H, int seq_len, int head_dim, float softmax_scale,
+                int dtype, int causal, void* stream)
+{
+    if (!Q || !K || !V || !O || !L) return FA2_ERR_NULL_POINTER;
+    int st = check_common(B, H, seq_len, head_dim, softmax_scale);
+    if (st) return st;
+    st = check_dim(head_dim, dtype);
+    if (st) return st;
+    if (dtype == FA2_DTYPE_BF16) {
+        fa2::FwdArgs a{};
+        a.Q = Q; a.K = K; a.V = V; a.O = O; a.L = L; a.Oacc = nullptr; a.M = nullptr;
+        a.BH = B * H; a.Nq = seq_len; a.Nk = seq_len; a.d = head_dim; a.scale = softmax_scale;
+        a.causal = causal ? 1 : 0; a.causal_shift = 0; a.resume = 0; a.finalize = 1;
+        return hip_status(fa2::launch_fwd_bf16(a, (hipStream_t)stream));
+    }
+    fa2::F32Args a{};
+    a.Q = (const float*)Q; a.K = (const float*)K; a.V = (const float*)V; a.O = (float*)O; a.L = L;
+    a.BH = B * H; a.N = seq_len; a.d = head_dim; a.scale = softmax_scale; a.causal = causal ? 1 : 0;
+    return hip_status(fa2::launch_fwd_f32(a, (hipStream_t)stream));
+}
+
+size_t fa2_backward_workspace_bytes(int B, int H, int seq_len, int head_dim, int dtype)
+{
+    (void)head_dim; (void)dtype;
+    if (B <= 0 || H <= 0 || seq_len <= 0) return 0;
+    return align256((size_t)B * H * seq_len * sizeof(float));   // D = rowsum(dO o O)
+}
+
+int fa2_backward(const void* Q, const void* K, const void* V, const void* O, const float* L,
+                 const void* dO, void* dQ, void* dK, void* dV,
+                 int B, int H, int seq_len, int head_dim, float softmax_scale,
+                 int dtype, int causal, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!Q || !K || !V || !O || !L || !dO || !dQ || !dK || !dV) return FA2_ERR_NULL_POINTER;
+    int st = check_common(B, H, seq_len, head_dim, softmax_scale);
+    if (st) return st;
+    st = check_dim(head_dim, dtype);
+    if (st) return st;
+    if (!workspace || workspace_bytes < fa2_backward_workspace_bytes(B, H, seq_len, head_dim, dtype))
+        return FA2_ERR_WORKSPACE;
+    if (dtype == FA2_DTYPE_BF16) {
+        fa2::BwdArgs a{};
+        a.Q = Q; a.K = K; a.V = V; a.O = O; a.dO = dO; a.L = L; a.dQ = dQ; a.dK = dK; a.dV = dV;
+        a.D = (float*)workspace; a.BH = B * H; a.N = seq_len; a.d = head_dim;
+        a.scale = softmax_scale; a.causal = causal ? 1 : 0;
+        return hip_status(fa2::launch_bwd_bf16(a, (hipStream_t)stream));
+    }
+    fa2::F32Args a{};
+    a.Q = (const float*)Q; a.K = (const float*)K; a.V = (const float*)V; a.O = (float*)O;
+    a.L = (float*)L; a.dO = (const float*)dO; a.dQ = (float*)dQ; a.dK = (float*)dK; a.dV = (float*)dV;
+    a.D = (float*)workspace; a.BH = B * H; a.N = seq_len; a.d = head_dim;
+    a.scale = softmax_scale; a.causal = causal ? 1 : 0;
+    return hip_status(fa2::launch_bwd_f32(a, (hipStream_t)stream));
+}
+
+int fa2_forward_step(const void* Q, const void* K, const void* V,
+                     void* O, float* L, float* Oacc, float* M,
+                     int B, int H, int q_len, int kv_len, int head_dim, float softmax_scale,
+                     int first, int last, void* stream)
+{
+    if (!Q || !K || !V || !L) return FA2_ERR_NULL_POINTER;
+    if (last && !O) return FA2_ERR_NULL_POINTER;
+    if ((!first || !last) && (!Oacc || !M)) return FA2_ERR_NULL_POINTER;
+    int st = check_common(B, H, q_len, head_dim, softmax_scale);
+    if (st) return st;
+    if (kv_len <= 0) return FA2_ERR_INVALID_SHAPE;
+    st = check_dim(head_dim, FA2_DTYPE_BF16);
+    if (st) return st;
+    fa2::FwdArgs a{};
+    a.Q = Q; a.K = K; a.V = V; a.O = O; a.L = L; a.Oacc = Oacc; a.M = M;
+    a.BH = B * H; a.Nq = q_len; a.Nk = kv_len; a.d = head_dim; a.scale = softmax_scale;
+    a.causal = 0; a.causal_shift = 0; a.resume = first ? 0 : 1; a.finalize = last ? 1 : 0;
+    return hip_status(fa2::launch_fwd_bf16(a, (hipStream_t)stream));
+}
+
+int flash_attention_2_forward(const float* Q, const float* K, const float* V,
+                              float* O, float* L, int seq_len, int head_dim, float softmax_scale)
+{
+    return fa2_forward(Q, K, V, O, L, 1, 1, seq_len, head_dim, softmax_scale, FA2_DTYPE_F32, 0, nullptr);
+}
+
+int flash_attention_2_backward(const float* Q, const float* K, const float* V,
+                               const float* O, const float* L, const float* dO,
+                               float* dQ, float* dK, float* dV,
+                               int seq_len, int head_dim, float softmax_scale)
+{
+    const size_t need = fa2_backward_workspace_bytes(1, 1, seq_len, head_dim, FA2_DTYPE_F32);
+    if (need == 0) return FA2_ERR_INVALID_SHAPE;
+    void* ws = nullptr;
+    int st = g_scratch.get(need, &ws);
+    if (st) return st;
+    return fa2_backward(Q, K, V, O, L, dO, dQ, dK, dV, 1, 1, seq_len, head_dim, softmax_scale,
+                        FA2_DTYPE_F32, 0, ws, need, nullptr);
+}
+
+int fa2_fill_f32(float* dst, size_t n, float value, void* stream)
+{
+    if (!dst && n) return FA2_ERR_NULL_POINTER;
+    return hip_status(fa2::launch_fill_f32(dst, n, value, (hipStream_t)stream));
+}
+
+int fa2_convert_f32_to_bf16(const float* src, void* dst, size_t n, void* stream)
+{
+    if ((!src || !dst) && n) return FA2_ERR_NULL_POINTER;
+    return hip_status(fa2::launch_f32_to_bf16(src, dst, n, (hipStream_t)stream));
+}
+
+int fa2_convert_bf16_to_f32(const void* src, float* dst, size_t n, void* stream)
+{
+    if ((!src || !dst) && n) return FA2_ERR_NULL_POINTER;
+    return hip_status(fa2::launch_bf16_to_f32(src, dst, n, (hipStream_t)stream));
+}
+
+}  // extern "C"

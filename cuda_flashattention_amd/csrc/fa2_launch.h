@@ -1,0 +1,59 @@
+// fa2_launch.h -- host-side launcher declarations (internal; the public surface is
+// include/fa2_mi355x.h).  Each launcher validates nothing: fa2_capi.cpp owns argument
+// checking and status codes, the launchers only pick a template instance and enqueue it.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+namespace fa2 {
+
+// One forward problem: BH independent [Nq, d] query slabs against [Nk, d] key/value slabs.
+// Plain attention has Nq == Nk; a ring step runs Nq local query rows against the Nk rows of
+// the resident K/V shard and carries (Oacc, Lrun, Mrun) between launches.
+struct FwdArgs {
+    const void* Q;    // [BH][Nq][d]   bf16
+    const void* K;    // [BH][Nk][d]   bf16
+    const void* V;    // [BH][Nk][d]   bf16
+    void* O;          // [BH][Nq][d]   bf16 (written when finalize != 0)
+    float* L;         // [BH][Nq]      natural-log LSE when finalize, running sum l otherwise
+    float* Oacc;      // [BH][Nq][d]   fp32 un-normalised accumulator (ring state) or nullptr
+    float* M;         // [BH][Nq]      running max in natural (scaled) units (ring state) or nullptr
+    int BH, Nq, Nk, d;
+    float scale;
+    int causal;       // keys j > i + causal_shift are masked
+    int causal_shift; // global key index of the shard's first key minus that of the first query
+    int resume;       // 1: start from (Oacc, L, M); 0: start from (0, 0, -inf)
+    int finalize;     // 1: write O = acc / l and L = m + ln l; 0: store state
+};
+
+hipError_t launch_fwd_bf16(const FwdArgs& a, hipStream_t stream);
+
+struct BwdArgs {
+    const void* Q; const void* K; const void* V; const void* O; const void* dO;  // bf16
+    const float* L;   // [BH][N] natural-log LSE from the forward
+    void* dQ; void* dK; void* dV;   // bf16
+    float* D;         // [BH][N] workspace: rowsum(dO o O)
+    int BH, N, d;
+    float scale;
+    int causal;
+};
+
+hipError_t launch_bwd_bf16(const BwdArgs& a, hipStream_t stream);
+
+// fp32 family (exact f32 MFMA, any d <= 128, any N): the reference-signature drop-ins.
+struct F32Args {
+    const float* Q; const float* K; const float* V; float* O; float* L;
+    const float* dO; float* dQ; float* dK; float* dV; float* D;
+    int BH, N, d;
+    float scale;
+    int causal;
+};
+hipError_t launch_fwd_f32(const F32Args& a, hipStream_t stream);
+hipError_t launch_bwd_f32(const F32Args& a, hipStream_t stream);
+
+// Element-wise helpers (fa2_util.hip).
+hipError_t launch_fill_f32(float* p, size_t n, float value, hipStream_t stream);
+hipError_t launch_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t stream);
+hipError_t launch_bf16_to_f32(const void* src, float* dst, size_t n, hipStream_t stream);
+
+}  // namespace fa2

@@ -1,0 +1,83 @@
+// fa2_util.hip -- small HBM-bound helpers around the attention kernels.
+//
+//   fill_f32      replaces init_array (reference src/util/cuda_helper.h:60-65): the -inf fill
+//                 of the ring's running max that memset cannot do (memo.md:1).
+//   f32 <-> bf16  conversions used by the fp32-in convenience paths of the C-ABI.
+// All are grid-stride, 16 bytes per lane per access.
+#include "fa2_common.h"
+#include "fa2_launch.h"
+
+namespace fa2 {
+
+__global__ void fill_f32_kernel(float* p, size_t n, float value)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t n4 = n / 4;
+    f32x4 v = {value, value, value, value};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+        reinterpret_cast<f32x4*>(p)[i] = v;
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = value;
+}
+
+__global__ void f32_to_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t n8 = n / 8;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(src)[2 * i];
+        const f32x4 b = reinterpret_cast<const f32x4*>(src)[2 * i + 1];
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] = (__bf16)a[e]; o[4 + e] = (__bf16)b[e]; }
+        reinterpret_cast<bf16x8*>(dst)[i] = o;
+    }
+    for (size_t i = n8 * 8 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        dst[i] = (__bf16)src[i];
+}
+
+__global__ void bf16_to_f32_kernel(const __bf16* __restrict__ src, float* __restrict__ dst, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t n8 = n / 8;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+        const bf16x8 v = reinterpret_cast<const bf16x8*>(src)[i];
+        f32x4 a, b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = (float)v[e]; b[e] = (float)v[4 + e]; }
+        reinterpret_cast<f32x4*>(dst)[2 * i] = a;
+        reinterpret_cast<f32x4*>(dst)[2 * i + 1] = b;
+    }
+    for (size_t i = n8 * 8 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        dst[i] = (float)src[i];
+}
+
+static unsigned grid_for(size_t items)
+{
+    size_t g = (items + 255) / 256;
+    if (g < 1) g = 1;
+    if (g > 2048) g = 2048;   // 256 CUs x 8 blocks, grid-stride the rest
+    return (unsigned)g;
+}
+
+hipError_t launch_fill_f32(float* p, size_t n, float value, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_f32_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, stream, p, n, value);
+    return hipGetLastError();
+}
+
+hipError_t launch_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n / 8 + 1)), dim3(256), 0, stream, src, (__bf16*)dst, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_bf16_to_f32(const void* src, float* dst, size_t n, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(grid_for(n / 8 + 1)), dim3(256), 0, stream, (const __bf16*)src, dst, n);
+    return hipGetLastError();
+}
+
+}  // namespace fa2

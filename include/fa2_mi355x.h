@@ -1,0 +1,114 @@
+/*
+ * fa2_mi355x.h -- C ABI of the MI355X-native FlashAttention-2 hot path (libfa2_mi355x.so).
+ *
+ * This is the drop-in boundary for the three host wrappers the reference
+ * (terryye/cuda_FlashAttention) calls from its test mains -- there is no registry or FFI in
+ * the reference, the wrappers ARE its operator interface:
+ *
+ *   flash_attention_2_forward   src/02_flash_attention_v2_forward/flash_attention_kernel.cu:300-309
+ *                               (cleaned copy src/03_flash_attention_v2_ring/common/flash_attention_kernel.cu:133-172)
+ *   flash_attention_2_backward  src/02_flash_attention_v2_backward/flash_attention_backward_kernel.cu:249-262
+ *   ring_attention_forward      src/03_flash_attention_v2_ring/common/ring_attention_kernel.cu:143-156
+ *                               (declared in fa2_ring_mi355x.h: it needs RCCL)
+ *
+ * Conventions (all entry points):
+ *   - plain C, raw DEVICE pointers and sizes, no framework types;
+ *   - tensors are contiguous row-major [B][H][N][d] ("head slabs" [N][d], each an independent
+ *     instance of the reference's single-head problem); L is [B][H][N] fp32 and holds the
+ *     NATURAL-log logsumexp of the scaled scores, exactly what the reference stores
+ *     (flash_attention_kernel.cu:291-294);
+ *   - the caller owns every tensor; the library never allocates in the extended entry points;
+ *   - stream-ordered and asynchronous: work is enqueued on `stream` (a hipStream_t passed as
+ *     void*; NULL = the default stream) and the call returns; nothing synchronises;
+ *   - return value: FA2_OK (0) or a negative status.  The library never aborts -- the
+ *     reference's assert()/exit() policy (cuda_helper.h:74-82, nccl_utils.h:11-18,
+ *     flash_attention_kernel.cu:317) becomes status codes.
+ */
+#ifndef FA2_MI355X_H
+#define FA2_MI355X_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------------------- */
+#define FA2_OK                     0
+#define FA2_ERR_NULL_POINTER      -1
+#define FA2_ERR_INVALID_SHAPE     -2   /* B, H, N <= 0, scale <= 0, ... */
+#define FA2_ERR_UNSUPPORTED_HEAD_DIM -3 /* bf16/fp8: d must be 64 or 128; fp32: 1 <= d <= 128 */
+#define FA2_ERR_UNSUPPORTED_DTYPE -4
+#define FA2_ERR_WORKSPACE         -5   /* workspace NULL or smaller than *_workspace_bytes() */
+#define FA2_ERR_UNSUPPORTED       -6   /* combination not implemented (e.g. causal ring) */
+#define FA2_ERR_HIP_BASE          -1000 /* -(1000 + hipError_t) */
+#define FA2_ERR_RCCL_BASE         -2000 /* -(2000 + ncclResult_t) */
+
+/* ---- element types of Q/K/V/O/dO/dQ/dK/dV -------------------------------------------- */
+#define FA2_DTYPE_BF16 0   /* primary: bf16 in, fp32 accumulate on v_mfma_f32_32x32x16_bf16 */
+#define FA2_DTYPE_F32  1   /* the reference's type: exact f32 MFMA (v_mfma_f32_32x32x2_f32)  */
+
+const char* fa2_version(void);
+const char* fa2_status_string(int status);
+
+/* ======================================================================================
+ * Reference-signature drop-ins: single head, fp32, default stream -- argument for argument
+ * the reference's wrappers, with `void` widened to an int status.  Any seq_len >= 1, any
+ * 1 <= head_dim <= 128 (the reference asserts head_dim <= 64 / 128).
+ * ==================================================================================== */
+
+/* replaces flash_attention_2_forward (02_forward/flash_attention_kernel.cu:300-309) */
+int flash_attention_2_forward(const float* Q, const float* K, const float* V,
+                              float* O, float* L,
+                              int seq_len, int head_dim, float softmax_scale);
+
+/* replaces flash_attention_2_backward (02_backward/flash_attention_backward_kernel.cu:249-262).
+ * Like the reference it overwrites dQ, dK, dV (the reference memsets dK, dV itself, :282-283).
+ * Scratch for D = rowsum(dO o O) comes from a per-device cache owned by the library. */
+int flash_attention_2_backward(const float* Q, const float* K, const float* V,
+                               const float* O, const float* L, const float* dO,
+                               float* dQ, float* dK, float* dV,
+                               int seq_len, int head_dim, float softmax_scale);
+
+/* ======================================================================================
+ * Extended entry points: (B, H), dtype, causal mask, stream.
+ * ==================================================================================== */
+
+/* O = softmax(scale * Q K^T [+ causal mask]) V ;  L = logsumexp rows.
+ * dtype BF16: Q,K,V,O bf16, d in {64,128}.  dtype F32: Q,K,V,O fp32, 1 <= d <= 128. */
+int fa2_forward(const void* Q, const void* K, const void* V, void* O, float* L,
+                int B, int H, int seq_len, int head_dim, float softmax_scale,
+                int dtype, int causal, void* stream);
+
+/* Bytes of scratch fa2_backward needs for this problem (D vector, fp32 staging). */
+size_t fa2_backward_workspace_bytes(int B, int H, int seq_len, int head_dim, int dtype);
+
+/* dQ, dK, dV from Q, K, V, O, L (forward outputs) and dO.  Deterministic: no atomics, every
+ * gradient element is produced by exactly one workgroup in a fixed summation order (the
+ * reference's smem + global atomicAdd scheme, flash_attention_backward_kernel.cu:208-231,
+ * is not reproduced). */
+int fa2_backward(const void* Q, const void* K, const void* V, const void* O, const float* L,
+                 const void* dO, void* dQ, void* dK, void* dV,
+                 int B, int H, int seq_len, int head_dim, float softmax_scale,
+                 int dtype, int causal, void* workspace, size_t workspace_bytes, void* stream);
+
+/* One resumable forward step: folds the Nk keys/values of a resident shard into the running
+ * state (Oacc fp32 un-normalised, Lrun = running sum l, Mrun = running max in natural
+ * units) of Nq local query rows -- the unit of work of ring_attention_forward_kernel
+ * (ring_attention_kernel.cu:13-140).  first != 0 starts from (0, 0, -inf) instead of loading
+ * the state; last != 0 writes O = Oacc / l (bf16) and L = m + ln l instead of storing it.
+ * bf16 only, d in {64,128}. */
+int fa2_forward_step(const void* Q, const void* K, const void* V,
+                     void* O, float* L, float* Oacc, float* M,
+                     int B, int H, int q_len, int kv_len, int head_dim, float softmax_scale,
+                     int first, int last, void* stream);
+
+/* Element-wise helpers (grid-stride, HBM-bound). */
+int fa2_fill_f32(float* dst, size_t n, float value, void* stream);      /* init_array, cuda_helper.h:60-65 */
+int fa2_convert_f32_to_bf16(const float* src, void* dst, size_t n, void* stream);
+int fa2_convert_bf16_to_f32(const void* src, float* dst, size_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FA2_MI355X_H */
