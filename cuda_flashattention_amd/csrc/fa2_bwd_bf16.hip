@@ -1,0 +1,458 @@
+// fa2_bwd_bf16.hip -- FlashAttention-2 backward for gfx950 (MI355X), bf16 in / fp32 accumulate.
+//
+// Replaces flash_attention_2_backward_kernel (reference
+// src/02_flash_attention_v2_backward/flash_attention_backward_kernel.cu:47-246): the same
+// maths -- D = rowsum(dO o O) (:97-120), P = exp(scale QK^T - L) (:157-173), dP = dO V^T
+// (:176-187), dS = P o (dP - D) (:190-193), dQ = scale dS K (:196-205), dV = P^T dO,
+// dK = scale dS^T Q (:208-221) -- but NOT its work split.  The reference is row-parallel and
+// sums dK/dV with shared-memory and global atomicAdd (:208-231), which serialises and is
+// order-dependent.  Here every gradient element is owned by exactly one wave:
+//
+//   kernel 0  fa2_bwd_delta      D[q] = sum_c dO[q][c] O[q][c]                (HBM-bound)
+//   kernel 1  fa2_bwd_dq         row-parallel (the forward's mapping): a workgroup owns 256
+//                                query rows, streams K/V tiles, keeps dQ^T in accumulators
+//   kernel 2  fa2_bwd_dkdv       column-parallel: a workgroup owns 256 keys (a wave 32 of
+//                                them, K/V fragments resident in registers), streams Q/dO
+//                                tiles, keeps dK^T and dV^T in accumulators
+//
+// No atomics, no memset, bitwise reproducible.  The price is that S and dP are formed in both
+// kernels (7 block products instead of 5); on MI355X the alternative -- fp32 atomics for dQ --
+// is bounded by the chip-wide float-atomic rate (~1.3 TB/s): dQ alone would be
+// B H (N/256) N d 4 B = 8.6 GB at (4,16,8192,128), a 6.6 ms floor, more than the two extra
+// products cost on the matrix cores.
+//
+// MFMA orientation (fa2_common.h): in kernel 1 the accumulator column (lane) is the query,
+// as in the forward; in kernel 2 it is the KEY, so that P[q][key] and dS[q][key], packed to
+// bf16 in registers, are directly the B operands of dV^T += dO^T P and dK^T += Q^T dS (both
+// contract over the accumulator's row index q) and dO^T / Q^T come from LDS through
+// ds_read_b64_tr_b16.  Row constants ride in the accumulators: kernel 2 starts the S chain
+// from -L/scale and the dP chain from -D, so p = exp2(c S') and dS = p dP' need no
+// per-element subtraction (rows are registers there, not lanes).
+#include "fa2_common.h"
+#include "fa2_launch.h"
+
+namespace fa2 {
+
+// --------------------------------------------------------------------------- kernel 0: D
+// 16 lanes per row (16 bytes of dO and of O each per step), 4 rows per wave.
+template <int D>
+__global__ void __launch_bounds__(256) fa2_bwd_delta_kernel(const __bf16* __restrict__ dO,
+                                                            const __bf16* __restrict__ O,
+                                                            float* __restrict__ Dv, size_t rows)
+{
+    const size_t row = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const int sub = threadIdx.x & 15;
+    float acc = 0.0f;
+    if (row < rows) {
+#pragma unroll
+        for (int c = sub * 8; c < D; c += 128) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(dO + row * D + c);
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(O + row * D + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += (float)a[e] * (float)b[e];
+        }
+    }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 16);
+    if (row < rows && sub == 0) Dv[row] = acc;
+}
+
+// --------------------------------------------------------------------------- kernel 1: dQ
+constexpr int kBwdRows = 256;   // query rows (kernel 1) / keys (kernel 2) per workgroup
+constexpr int kDqKV = 64;       // keys per streamed tile in kernel 1
+constexpr int kDkQ = 32;        // query rows per streamed tile in kernel 2
+
+template <int D, bool CAUSAL>
+__global__ void __launch_bounds__(512, 2) fa2_bwd_dq_kernel(BwdArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ROWB = D * 2;
+    constexpr int TILEB = kDqKV * ROWB;
+    constexpr int CPR = D / 8;
+    constexpr int CPT = kDqKV * CPR / 512;
+    constexpr int KS = D / 16;
+    constexpr int DT = D / 32;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qi = lane & 31;
+    const int h = lane >> 5;
+    const int N = p.N;
+
+    const int nrb = (N + kBwdRows - 1) / kBwdRows;
+    int head, rb;
+    map_block(blockIdx.x, p.BH, nrb, head, rb);
+    if (CAUSAL) rb = nrb - 1 - rb;
+
+    const size_t slab = (size_t)head * N * ROWB;
+    const char* Qh = (const char*)p.Q + slab;
+    const char* Kh = (const char*)p.K + slab;
+    const char* Vh = (const char*)p.V + slab;
+    const char* Gh = (const char*)p.dO + slab;
+
+    const int q0 = rb * kBwdRows + wave * 32;
+    const int qrow = q0 + qi;
+    const int qld = qrow < N ? qrow : N - 1;
+
+    int ntiles = (N + kDqKV - 1) / kDqKV;
+    if (CAUSAL) ntiles = min(ntiles, min(rb * kBwdRows + kBwdRows - 1, N - 1) / kDqKV + 1);
+
+    bf16x8 qf[KS], gf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        qf[s] = *reinterpret_cast<const bf16x8*>(Qh + (size_t)qld * ROWB + 16 * (2 * s + h));
+        gf[s] = *reinterpret_cast<const bf16x8*>(Gh + (size_t)qld * ROWB + 16 * (2 * s + h));
+    }
+    const float Lq = p.L[(size_t)head * N + qld] * kLog2e;
+    const float Dq = p.D[(size_t)head * N + qld];
+    const float c2 = p.scale * kLog2e;
+
+    f32x16 dqacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dqacc[dt][r] = 0.0f;
+
+    u32x4 kreg[CPT], vreg[CPT];
+    auto stage_load = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = tid + 512 * i;
+            const int row = c / CPR, ch = c % CPR;
+            int krow = t * kDqKV + row;
+            krow = krow < N ? krow : N - 1;
+            kreg[i] = *reinterpret_cast<const u32x4*>(Kh + (size_t)krow * ROWB + 16 * ch);
+            vreg[i] = *reinterpret_cast<const u32x4*>(Vh + (size_t)krow * ROWB + 16 * ch);
+        }
+    };
+    auto stage_write = [&](int buf) {
+        char* kb = smem + buf * 2 * TILEB;
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = tid + 512 * i;
+            const int row = c / CPR, ch = c % CPR;
+            const int o = lds_off<D>(row, ch);
+            *reinterpret_cast<u32x4*>(kb + o) = kreg[i];
+            *reinterpret_cast<u32x4*>(kb + TILEB + o) = vreg[i];
+        }
+    };
+
+    if (ntiles > 0) {
+        stage_load(0);
+        stage_write(0);
+    }
+    __syncthreads();
+
+    const int trq = (lane & 15) >> 2;
+    const int trp = lane & 3;
+    const int trcb = (lane >> 4) & 1;
+
+    for (int t = 0; t < ntiles; ++t) {
+        const char* Kt = smem + (t & 1) * 2 * TILEB;
+        const char* Vt = Kt + TILEB;
+        const bool more = t + 1 < ntiles;
+        if (more) stage_load(t + 1);
+
+        const int key0 = t * kDqKV;
+        bool active = true;
+        if (CAUSAL) active = key0 <= q0 + 31;
+
+        if (active) {
+            const bool tail = key0 + kDqKV > N;
+            bool diag = false;
+            if (CAUSAL) diag = key0 + kDqKV - 1 > q0;
+
+            bf16x8 dsf[2][2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                f32x16 sacc, dpacc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { sacc[r] = 0.0f; dpacc[r] = 0.0f; }
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const int o = lds_off<D>(32 * kb + qi, 2 * s + h);
+                    sacc = mfma32(lds_read_frag(Kt, o), qf[s], sacc);     // S^T[key][q]
+                    dpacc = mfma32(lds_read_frag(Vt, o), gf[s], dpacc);   // dP^T[key][q]
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float pr = __builtin_amdgcn_exp2f(sacc[r] * c2 - Lq);
+                    if (tail || diag) {
+                        const int key = key0 + 32 * kb + acc_row(r, h);
+                        bool dead = key >= N;
+                        if (CAUSAL) dead = dead || key > qrow;
+                        if (dead) pr = 0.0f;
+                    }
+                    sacc[r] = pr * (dpacc[r] - Dq);                        // dS^T[key][q]
+                }
+                dsf[kb][0] = pack_acc(sacc, 0);
+                dsf[kb][1] = pack_acc(sacc, 1);
+            }
+
+            // dQ^T[dcol][q] += K^T[dcol][key] dS^T[key][q]
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int sp = 0; sp < 2; ++sp) {
+                        bf16x4 part[2];
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) {
+                            const int row = 32 * kb + 16 * sp + 8 * jj + 4 * h + trq;
+                            const int ch = 4 * dt + 2 * trcb + (trp >> 1);
+                            part[jj] = lds_read_tr(Kt, lds_off<D>(row, ch) + 8 * (trp & 1));
+                        }
+                        bf16x8 kf;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { kf[e] = part[0][e]; kf[4 + e] = part[1][e]; }
+                        dqacc[dt] = mfma32(kf, dsf[kb][sp], dqacc[dt]);
+                    }
+        }
+
+        if (more) stage_write((t + 1) & 1);
+        __syncthreads();
+    }
+
+    if (qrow < N) {
+        char* dQq = (char*)p.dQ + slab + (size_t)qrow * ROWB;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (__bf16)(dqacc[dt][4 * g + e] * p.scale);
+                *reinterpret_cast<bf16x4*>(dQq + 2 * (32 * dt + 8 * g + 4 * h)) = o;
+            }
+    }
+}
+
+// --------------------------------------------------------------------------- kernel 2: dK, dV
+template <int D, bool CAUSAL>
+__global__ void __launch_bounds__(512, 2) fa2_bwd_dkdv_kernel(BwdArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ROWB = D * 2;
+    constexpr int TILEB = kDkQ * ROWB;          // bytes per Q (or dO) tile: 32 rows
+    constexpr int BUFB = 2 * TILEB + 256;       // Q tile, dO tile, 32 x (-L/scale), 32 x (-D)
+    constexpr int CPR = D / 8;
+    constexpr int NCH = kDkQ * CPR;             // chunks per tile: 512 (D=128) or 256 (D=64)
+    constexpr int KS = D / 16;
+    constexpr int DT = D / 32;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ki = lane & 31;
+    const int h = lane >> 5;
+    const int N = p.N;
+
+    const int ncb = (N + kBwdRows - 1) / kBwdRows;
+    int head, cb;
+    map_block(blockIdx.x, p.BH, ncb, head, cb);     // causal: key block 0 is the heaviest, already first
+
+    const size_t slab = (size_t)head * N * ROWB;
+    const char* Qh = (const char*)p.Q + slab;
+    const char* Kh = (const char*)p.K + slab;
+    const char* Vh = (const char*)p.V + slab;
+    const char* Gh = (const char*)p.dO + slab;
+    const float* Lh = p.L + (size_t)head * N;
+    const float* Dh = p.D + (size_t)head * N;
+
+    const int k0 = cb * kBwdRows + wave * 32;       // first key of this wave
+    const int key = k0 + ki;
+    const int kld = key < N ? key : N - 1;
+
+    // K, V fragments: B operands of S = Q K^T and dP = dO V^T (lane = key column).
+    bf16x8 kf[KS], vf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        kf[s] = *reinterpret_cast<const bf16x8*>(Kh + (size_t)kld * ROWB + 16 * (2 * s + h));
+        vf[s] = *reinterpret_cast<const bf16x8*>(Vh + (size_t)kld * ROWB + 16 * (2 * s + h));
+    }
+
+    f32x16 dkacc[DT], dvacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dkacc[dt][r] = 0.0f; dvacc[dt][r] = 0.0f; }
+
+    const int ntiles = (N + kDkQ - 1) / kDkQ;
+    int t0 = 0;
+    if (CAUSAL) t0 = (cb * kBwdRows) / kDkQ;        // earlier query rows see none of these keys
+
+    const float c2 = p.scale * kLog2e;
+    const float inv_scale = 1.0f / p.scale;
+
+    // staging: thread -> one 16-byte chunk of the Q tile or of the dO tile (D=128: both).
+    constexpr int CPT = 2 * NCH / 512;              // 2 (D=128) or 1 (D=64)
+    u32x4 sreg[CPT];
+    float rc = 0.0f;                                 // row constant carried by threads 0..63
+    auto stage_load = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = tid + 512 * i;             // 0 .. 2*NCH-1 : first NCH = Q, rest = dO
+            const int which = c / NCH, cc = c % NCH;
+            const int row = cc / CPR, ch = cc % CPR;
+            int qr = t * kDkQ + row;
+            qr = qr < N ? qr : N - 1;
+            const char* src = which ? Gh : Qh;
+            sreg[i] = *reinterpret_cast<const u32x4*>(src + (size_t)qr * ROWB + 16 * ch);
+        }
+        if (tid < 64) {
+            int qr = t * kDkQ + (tid & 31);
+            qr = qr < N ? qr : N - 1;
+            rc = tid < 32 ? -Lh[qr] * inv_scale : -Dh[qr];
+        }
+    };
+    auto stage_write = [&](int buf) {
+        char* b = smem + buf * BUFB;
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = tid + 512 * i;
+            const int which = c / NCH, cc = c % NCH;
+            const int row = cc / CPR, ch = cc % CPR;
+            *reinterpret_cast<u32x4*>(b + which * TILEB + lds_off<D>(row, ch)) = sreg[i];
+        }
+        if (tid < 64) reinterpret_cast<float*>(b + 2 * TILEB)[tid] = rc;
+    };
+
+    if (t0 < ntiles) {
+        stage_load(t0);
+        stage_write(t0 & 1);
+    }
+    __syncthreads();
+
+    const int trq = (lane & 15) >> 2;
+    const int trp = lane & 3;
+    const int trcb = (lane >> 4) & 1;
+
+    for (int t = t0; t < ntiles; ++t) {
+        const char* Qt = smem + (t & 1) * BUFB;
+        const char* Gt = Qt + TILEB;
+        const float* rcs = reinterpret_cast<const float*>(Qt + 2 * TILEB);
+        const bool more = t + 1 < ntiles;
+        if (more) stage_load(t + 1);
+
+        const int qb0 = t * kDkQ;
+        bool active = true;
+        if (CAUSAL) active = qb0 + kDkQ - 1 >= k0;     // some query row sees some key of this wave
+
+        if (active) {
+            // accumulators start from the row constants: S' = Q K^T - L/scale, dP' = dO V^T - D
+            f32x16 sacc, dpacc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(rcs + 8 * g + 4 * h);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(rcs + 32 + 8 * g + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sacc[4 * g + e] = a[e]; dpacc[4 * g + e] = b[e]; }
+            }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int o = lds_off<D>(ki, 2 * s + h);                 // row = query (A operand row = lane & 31)
+                sacc = mfma32(lds_read_frag(Qt, o), kf[s], sacc);        // S'[q][key]
+                dpacc = mfma32(lds_read_frag(Gt, o), vf[s], dpacc);      // dP'[q][key]
+            }
+            const bool tail = qb0 + kDkQ > N;
+            bool diag = false;
+            if (CAUSAL) diag = qb0 < k0 + 31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float pr = __builtin_amdgcn_exp2f(sacc[r] * c2);
+                if (tail || diag) {
+                    const int q = qb0 + acc_row(r, h);
+                    bool dead = q >= N;
+                    if (CAUSAL) dead = dead || key > q;
+                    if (dead) pr = 0.0f;
+                }
+                sacc[r] = pr;                        // P[q][key]
+                dpacc[r] = pr * dpacc[r];            // dS[q][key]
+            }
+            bf16x8 pf[2], dsf[2];
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) { pf[sp] = pack_acc(sacc, sp); dsf[sp] = pack_acc(dpacc, sp); }
+
+            // dV^T[dcol][key] += dO^T[dcol][q] P[q][key];  dK^T[dcol][key] += Q^T[dcol][q] dS[q][key]
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp) {
+                    bf16x4 gp[2], qp[2];
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int row = 16 * sp + 8 * jj + 4 * h + trq;
+                        const int ch = 4 * dt + 2 * trcb + (trp >> 1);
+                        const int o = lds_off<D>(row, ch) + 8 * (trp & 1);
+                        gp[jj] = lds_read_tr(Gt, o);
+                        qp[jj] = lds_read_tr(Qt, o);
+                    }
+                    bf16x8 gT, qT;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        gT[e] = gp[0][e]; gT[4 + e] = gp[1][e];
+                        qT[e] = qp[0][e]; qT[4 + e] = qp[1][e];
+                    }
+                    dvacc[dt] = mfma32(gT, pf[sp], dvacc[dt]);
+                    dkacc[dt] = mfma32(qT, dsf[sp], dkacc[dt]);
+                }
+        }
+
+        if (more) stage_write((t + 1) & 1);
+        __syncthreads();
+    }
+
+    if (key < N) {
+        char* dKk = (char*)p.dK + slab + (size_t)key * ROWB;
+        char* dVk = (char*)p.dV + slab + (size_t)key * ROWB;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 a, b;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a[e] = (__bf16)(dkacc[dt][4 * g + e] * p.scale);
+                    b[e] = (__bf16)dvacc[dt][4 * g + e];
+                }
+                *reinterpret_cast<bf16x4*>(dKk + 2 * (32 * dt + 8 * g + 4 * h)) = a;
+                *reinterpret_cast<bf16x4*>(dVk + 2 * (32 * dt + 8 * g + 4 * h)) = b;
+            }
+    }
+}
+
+// --------------------------------------------------------------------------- launch
+template <int D, bool CAUSAL>
+static hipError_t launch_bwd_one(const BwdArgs& a, hipStream_t stream)
+{
+    const size_t rows = (size_t)a.BH * a.N;
+    hipLaunchKernelGGL((fa2_bwd_delta_kernel<D>), dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0,
+                       stream, (const __bf16*)a.dO, (const __bf16*)a.O, a.D, rows);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+
+    const int nb = (a.N + kBwdRows - 1) / kBwdRows;
+    constexpr int lds_dq = 2 * 2 * kDqKV * D * 2;
+    constexpr int lds_dk = 2 * (2 * kDkQ * D * 2 + 256);
+    static bool set_dq[64] = {}, set_dk[64] = {};
+    e = ensure_dynamic_lds(fa2_bwd_dq_kernel<D, CAUSAL>, lds_dq, set_dq);
+    if (e != hipSuccess) return e;
+    e = ensure_dynamic_lds(fa2_bwd_dkdv_kernel<D, CAUSAL>, lds_dk, set_dk);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((fa2_bwd_dq_kernel<D, CAUSAL>), dim3((unsigned)(nb * a.BH)), dim3(512), lds_dq, stream, a);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((fa2_bwd_dkdv_kernel<D, CAUSAL>), dim3((unsigned)(nb * a.BH)), dim3(512), lds_dk, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_bwd_bf16(const BwdArgs& a, hipStream_t stream)
+{
+    if (a.d == 128) return a.causal ? launch_bwd_one<128, true>(a, stream) : launch_bwd_one<128, false>(a, stream);
+    if (a.d == 64) return a.causal ? launch_bwd_one<64, true>(a, stream) : launch_bwd_one<64, false>(a, stream);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace fa2

@@ -287,16 +287,9 @@ static hipError_t launch_one(const FwdArgs& a, hipStream_t stream)
 {
     constexpr int lds = 2 * 2 * kFwdKV * D * 2;
     auto kern = fa2_fwd_bf16_kernel<D, CAUSAL, STATE>;
-    static bool attr_set[64] = {};   // per device; benign race: the attribute is idempotent
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
+    static bool attr_set[64] = {};
+    hipError_t e = ensure_dynamic_lds(kern, lds, attr_set);
     if (e != hipSuccess) return e;
-    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return e;
-        attr_set[dev] = true;
-    }
     const int nrb = (a.Nq + kFwdRows - 1) / kFwdRows;
     const dim3 grid((unsigned)(nrb * a.BH));
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, a);

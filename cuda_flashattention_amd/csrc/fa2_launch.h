@@ -51,6 +51,24 @@ struct F32Args {
 hipError_t launch_fwd_f32(const F32Args& a, hipStream_t stream);
 hipError_t launch_bwd_f32(const F32Args& a, hipStream_t stream);
 
+// Raises the dynamic-LDS limit of `kern` on the current device once (per template instance:
+// pass a function-local static flag array).  Benign race: the attribute is idempotent.
+template <typename Kern>
+inline hipError_t ensure_dynamic_lds(Kern kern, int bytes, bool (&done)[64])
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!done[dev]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+        done[dev] = true;
+    }
+    return hipSuccess;
+}
+
 // Element-wise helpers (fa2_util.hip).
 hipError_t launch_fill_f32(float* p, size_t n, float value, hipStream_t stream);
 hipError_t launch_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t stream);

@@ -1,7 +1,6 @@
 // Launchers not written yet return hipErrorNotSupported (removed as each family lands).
 #include "fa2_launch.h"
 namespace fa2 {
-hipError_t launch_bwd_bf16(const BwdArgs&, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_fwd_f32(const F32Args&, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_bwd_f32(const F32Args&, hipStream_t) { return hipErrorNotSupported; }
 }
