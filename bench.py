@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- FA2 fwd+bwd TFLOP/s at (B=4,H=16,N=8192,d=128) on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of synthetic bf16 Q/K/V/dO already
+resident in HBM: fa2_forward then fa2_backward (delta + dQ + dK/dV kernels) through the C ABI
+of libfa2_mi355x.so.  W untimed warm-up steps, then EXACTLY K steps bracketed by a barrier +
+torch.cuda.synchronize() on both sides; rank 0 prints ONE JSON line.
+
+N > 1 ranks: the path shards over independent (batch, head) slabs with no data-path
+collective, so every rank runs the full (4,16,8192,128) batch of its own ("weak" scaling) and
+`value` is the total flops of all ranks / the slowest rank's time.  The sequence-sharded ring
+forward (the path's one real exchange step, RCCL send/recv over xGMI) is timed afterwards and
+reported in the extra "ring" object when the ring library is available.
+
+Flop model: fwd 4 B H N^2 d, bwd 10 B H N^2 d (five block products), fwd+bwd 14.
+The backward here executes seven products (S and dP are formed in both of its kernels,
+DESIGN.md); the metric still counts the algorithmic ten.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2516.6   # MI355X dense bf16 MFMA: 256 CU x 4096 flop/clk x 2.4 GHz
+B, H, N, D = 4, 16, 8192, 128
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ring", action="store_true")
+    return ap.parse_args()
+
+
+def timed(fn, iters, torch):
+    """Average milliseconds per call, HIP events on the stream the kernels are launched on
+    (torch's current stream is what the C ABI receives)."""
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def cpu_baseline(torch):
+    """The oracle (a port of the reference's naive CPU attention, oracle/naive_attention.c)
+    timed on this host: forward + backward share of every 2nd query row of ONE head of the
+    bench workload (4096 rows x 14 N d flops), all cores."""
+    import numpy as np
+    import oracle
+    rng = np.random.default_rng(0)
+    Q, K, V = (rng.uniform(-0.5, 0.5, (N, D)).astype(np.float32) for _ in range(3))
+    dO = rng.uniform(-0.2, 0.2, (N, D)).astype(np.float32)
+    cores = oracle.get_threads()
+    oracle.fwdbwd_rows(Q[:256], K[:256], V[:256], dO[:256], 0.0, (0, 1))   # page in / warm
+    stride = 2
+    t0 = time.perf_counter()
+    oracle.fwdbwd_rows(Q, K, V, dO, 0.0, (0, stride))
+    dt = time.perf_counter() - t0
+    rows = len(range(0, N, stride))
+    flops = 14.0 * N * D * rows
+    return {"value": flops / dt / 1e12, "unit": "TFLOP/s", "cores": cores, "kind": "port",
+            "sample": f"fwd+bwd share of {rows} of {N} query rows of 1 of {B * H} heads "
+                      f"(N={N}, d={D}, fp32, {flops / 1e9:.1f} GFLOP in {dt:.2f} s)"}
+
+
+def main():
+    args = parse()
+    import torch
+    import cuda_flashattention_amd as fa
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    torch.cuda.set_device(local % torch.cuda.device_count())
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    mk = lambda s: ((torch.rand(B, H, N, D, device=dev, generator=g) - 0.5) * s).to(torch.bfloat16)
+    Q, K, V, dO = mk(1.0), mk(1.0), mk(1.0), mk(0.4)   # the reference's value ranges (main.cu:30-32, :226)
+    O = torch.empty_like(Q)
+    L = torch.empty(B, H, N, dtype=torch.float32, device=dev)
+    dQ, dK, dV = torch.empty_like(Q), torch.empty_like(Q), torch.empty_like(Q)
+    ws = torch.empty(fa._capi.lib().fa2_backward_workspace_bytes(B, H, N, D, 0), dtype=torch.uint8, device=dev)
+    scale = 1.0 / D ** 0.5
+
+    def fwd():
+        fa.flash_attention_2_forward(Q, K, V, scale, O=O, L=L)
+
+    def bwd(phases=7):
+        fa.flash_attention_2_backward(Q, K, V, O, L, dO, scale, dQ=dQ, dK=dK, dV=dV, workspace=ws, phases=phases)
+
+    def step():
+        fwd()
+        bwd()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    flops_step = 14.0 * B * H * N * N * D
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * flops_step / (ms_per_step * 1e-3) / 1e12
+
+    # ---- per-kernel launch durations (HIP events, same stream), for the roofline object
+    it = max(3, min(args.steps, 10))
+    k_ms = {
+        "fa2_fwd_bf16_kernel": timed(fwd, it, torch),
+        "fa2_bwd_delta_kernel": timed(lambda: bwd(1), it, torch),
+        "fa2_bwd_dq_kernel": timed(lambda: bwd(2), it, torch),
+        "fa2_bwd_dkdv_kernel": timed(lambda: bwd(4), it, torch),
+    }
+    # MFMA flops each launch executes: fwd 2 block products, dq 3 (S, dP, dQ), dkdv 4 (S, dP, dV, dK)
+    prod = 2.0 * B * H * N * N * D
+    k_flops = {"fa2_fwd_bf16_kernel": 2 * prod, "fa2_bwd_dq_kernel": 3 * prod, "fa2_bwd_dkdv_kernel": 4 * prod}
+    dom = max(k_flops, key=lambda k: k_ms[k])
+    achieved = k_flops[dom] / (k_ms[dom] * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "flops_per_launch": k_flops[dom], "ms_per_launch": round(k_ms[dom], 4),
+                "kernels_ms": {k: round(v, 4) for k, v in k_ms.items()},
+                "whole_path_frac": round(value / world / PEAK_BF16_TFLOPS, 4)}
+
+    out = {
+        "metric": "FA2 fwd+bwd TFLOP/s at (B=4,H=16,N=8192,d=128); % MFMA peak",
+        "value": round(value, 2), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "FA2 forward+backward bf16, (B=4,H=16,N=8192,d=128) per GPU, non-causal "
+                               "(BASELINE configs[2]); flops = 14 B H N^2 d",
+                   "B": B, "H": H, "N": N, "d": D, "parallelism": f"head-sharded replicas x{world}"},
+        "pct_mfma_peak": round(100.0 * value / world / PEAK_BF16_TFLOPS, 2),
+        "roofline": roofline,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(torch)
+        except Exception as e:  # the baseline is a reported side figure, never fatal
+            out["cpu_baseline"] = {"error": repr(e)}
+
+    if not args.no_ring:
+        try:
+            from cuda_flashattention_amd import ring
+            r = ring.bench_ring(dist, rank, world, steps=max(2, min(args.steps, 5)), warmup=1)
+            if r is not None:
+                out["ring"] = r
+        except Exception as e:
+            out["ring"] = {"error": repr(e)}
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

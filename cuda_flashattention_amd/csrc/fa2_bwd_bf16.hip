@@ -428,11 +428,13 @@ template <int D, bool CAUSAL>
 static hipError_t launch_bwd_one(const BwdArgs& a, hipStream_t stream)
 {
     const size_t rows = (size_t)a.BH * a.N;
-    hipLaunchKernelGGL((fa2_bwd_delta_kernel<D>), dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0,
-                       stream, (const __bf16*)a.dO, (const __bf16*)a.O, a.D, rows);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-
+    hipError_t e = hipSuccess;
+    if (a.phases & 1) {
+        hipLaunchKernelGGL((fa2_bwd_delta_kernel<D>), dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0,
+                           stream, (const __bf16*)a.dO, (const __bf16*)a.O, a.D, rows);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
     const int nb = (a.N + kBwdRows - 1) / kBwdRows;
     constexpr int lds_dq = 2 * 2 * kDqKV * D * 2;
     constexpr int lds_dk = 2 * (2 * kDkQ * D * 2 + 256);
@@ -441,11 +443,16 @@ static hipError_t launch_bwd_one(const BwdArgs& a, hipStream_t stream)
     if (e != hipSuccess) return e;
     e = ensure_dynamic_lds(fa2_bwd_dkdv_kernel<D, CAUSAL>, lds_dk, set_dk);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((fa2_bwd_dq_kernel<D, CAUSAL>), dim3((unsigned)(nb * a.BH)), dim3(512), lds_dq, stream, a);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((fa2_bwd_dkdv_kernel<D, CAUSAL>), dim3((unsigned)(nb * a.BH)), dim3(512), lds_dk, stream, a);
-    return hipGetLastError();
+    if (a.phases & 2) {
+        hipLaunchKernelGGL((fa2_bwd_dq_kernel<D, CAUSAL>), dim3((unsigned)(nb * a.BH)), dim3(512), lds_dq, stream, a);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    if (a.phases & 4) {
+        hipLaunchKernelGGL((fa2_bwd_dkdv_kernel<D, CAUSAL>), dim3((unsigned)(nb * a.BH)), dim3(512), lds_dk, stream, a);
+        e = hipGetLastError();
+    }
+    return e;
 }
 
 hipError_t launch_bwd_bf16(const BwdArgs& a, hipStream_t stream)

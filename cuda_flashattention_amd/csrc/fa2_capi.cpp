@@ -115,6 +115,16 @@ int fa2_backward(const void* Q, const void* K, const void* V, const void* O, con
                  int B, int H, int seq_len, int head_dim, float softmax_scale,
                  int dtype, int causal, void* workspace, size_t workspace_bytes, void* stream)
 {
+    return fa2_backward_phases(Q, K, V, O, L, dO, dQ, dK, dV, B, H, seq_len, head_dim, softmax_scale,
+                               dtype, causal, workspace, workspace_bytes, stream, 7);
+}
+
+int fa2_backward_phases(const void* Q, const void* K, const void* V, const void* O, const float* L,
+                        const void* dO, void* dQ, void* dK, void* dV,
+                        int B, int H, int seq_len, int head_dim, float softmax_scale,
+                        int dtype, int causal, void* workspace, size_t workspace_bytes, void* stream,
+                        int phases)
+{
     if (!Q || !K || !V || !O || !L || !dO || !dQ || !dK || !dV) return FA2_ERR_NULL_POINTER;
     int st = check_common(B, H, seq_len, head_dim, softmax_scale);
     if (st) return st;
@@ -126,14 +136,14 @@ int fa2_backward(const void* Q, const void* K, const void* V, const void* O, con
         fa2::BwdArgs a{};
         a.Q = Q; a.K = K; a.V = V; a.O = O; a.dO = dO; a.L = L; a.dQ = dQ; a.dK = dK; a.dV = dV;
         a.D = (float*)workspace; a.BH = B * H; a.N = seq_len; a.d = head_dim;
-        a.scale = softmax_scale; a.causal = causal ? 1 : 0;
+        a.scale = softmax_scale; a.causal = causal ? 1 : 0; a.phases = phases & 7;
         return hip_status(fa2::launch_bwd_bf16(a, (hipStream_t)stream));
     }
     fa2::F32Args a{};
     a.Q = (const float*)Q; a.K = (const float*)K; a.V = (const float*)V; a.O = (float*)O;
     a.L = (float*)L; a.dO = (const float*)dO; a.dQ = (float*)dQ; a.dK = (float*)dK; a.dV = (float*)dV;
     a.D = (float*)workspace; a.BH = B * H; a.N = seq_len; a.d = head_dim;
-    a.scale = softmax_scale; a.causal = causal ? 1 : 0;
+    a.scale = softmax_scale; a.causal = causal ? 1 : 0; a.phases = phases & 7;
     return hip_status(fa2::launch_bwd_f32(a, (hipStream_t)stream));
 }
 

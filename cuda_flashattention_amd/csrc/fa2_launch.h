@@ -36,6 +36,7 @@ struct BwdArgs {
     int BH, N, d;
     float scale;
     int causal;
+    int phases;       // bit 0: D = rowsum(dO o O), bit 1: dQ kernel, bit 2: dK/dV kernel (7 = all)
 };
 
 hipError_t launch_bwd_bf16(const BwdArgs& a, hipStream_t stream);
@@ -47,6 +48,7 @@ struct F32Args {
     int BH, N, d;
     float scale;
     int causal;
+    int phases;       // backward only, as BwdArgs::phases
 };
 hipError_t launch_fwd_f32(const F32Args& a, hipStream_t stream);
 hipError_t launch_bwd_f32(const F32Args& a, hipStream_t stream);

@@ -59,7 +59,7 @@ def flash_attention_2_forward(Q, K, V, softmax_scale=None, causal=False, O=None,
 
 
 def flash_attention_2_backward(Q, K, V, O, L, dO, softmax_scale=None, causal=False,
-                               dQ=None, dK=None, dV=None, workspace=None, stream=None):
+                               dQ=None, dK=None, dV=None, workspace=None, stream=None, phases=7):
     """dQ, dK, dV = FA2 backward.  Mirrors flash_attention_2_backward(Q,K,V,O,L,dO,dQ,dK,dV,...)
     (reference 02_backward/flash_attention_backward_kernel.cu:249-262)."""
     B, H, N, d = _bhnd(Q, "Q")
@@ -71,11 +71,11 @@ def flash_attention_2_backward(Q, K, V, O, L, dO, softmax_scale=None, causal=Fal
     need = lib.fa2_backward_workspace_bytes(B, H, N, d, _dtype_code(Q))
     if workspace is None:
         workspace = torch.empty(need, dtype=torch.uint8, device=Q.device)
-    st = lib.fa2_backward(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), L.data_ptr(),
-                          dO.data_ptr(), dQ.data_ptr(), dK.data_ptr(), dV.data_ptr(),
-                          B, H, N, d, scale, _dtype_code(Q), 1 if causal else 0,
-                          workspace.data_ptr(), workspace.numel() * workspace.element_size(),
-                          _stream_ptr(stream))
+    st = lib.fa2_backward_phases(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), L.data_ptr(),
+                                 dO.data_ptr(), dQ.data_ptr(), dK.data_ptr(), dV.data_ptr(),
+                                 B, H, N, d, scale, _dtype_code(Q), 1 if causal else 0,
+                                 workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+                                 _stream_ptr(stream), int(phases))
     check(st, "fa2_backward")
     return dQ, dK, dV
 

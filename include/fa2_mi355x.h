@@ -92,6 +92,16 @@ int fa2_backward(const void* Q, const void* K, const void* V, const void* O, con
                  int B, int H, int seq_len, int head_dim, float softmax_scale,
                  int dtype, int causal, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same, restricted to some of its three kernels -- bit 0: D = rowsum(dO o O) into the
+ * workspace, bit 1: dQ, bit 2: dK and dV (7 = fa2_backward).  For profiling and for callers
+ * that overlap the two independent main kernels on separate streams; bits 1 and 2 need the
+ * D that bit 0 produced in the same workspace. */
+int fa2_backward_phases(const void* Q, const void* K, const void* V, const void* O, const float* L,
+                        const void* dO, void* dQ, void* dK, void* dV,
+                        int B, int H, int seq_len, int head_dim, float softmax_scale,
+                        int dtype, int causal, void* workspace, size_t workspace_bytes, void* stream,
+                        int phases);
+
 /* One resumable forward step: folds the Nk keys/values of a resident shard into the running
  * state (Oacc fp32 un-normalised, Lrun = running sum l, Mrun = running max in natural
  * units) of Nq local query rows -- the unit of work of ring_attention_forward_kernel

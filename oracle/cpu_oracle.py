@@ -116,8 +116,6 @@ def ref_self_test():
 # ---------------------------------------------------------------- family 2 (scalable, f64 accumulation)
 def _as_slabs(x):
     x = _f32(x)
-    if x.ndim == 2:
-        x = x[None]
     lead = x.shape[:-2]
     return x.reshape((-1,) + x.shape[-2:]), lead
 
@@ -180,3 +178,30 @@ def set_threads(n):
         return True
     except OSError:
         return False
+
+
+def fwdbwd_rows(Q, K, V, dO, scale=0.0, rows=(0, 1)):
+    """cpu_baseline sample: forward + backward share of a strided row set of one [N,d] head
+    (14 N d flops per row).  Returns (O_rows, dQ_rows, dK_partial, dV_partial)."""
+    Q, K, V, dO = _f32(Q), _f32(K), _f32(V), _f32(dO)
+    N, d = Q.shape
+    row0, stride = rows
+    n = len(range(row0, N, stride))
+    O = np.empty((n, d), np.float32)
+    dQ = np.empty((n, d), np.float32)
+    dK = np.empty_like(Q)
+    dV = np.empty_like(Q)
+    fn = _oracle().oracle_fwdbwd_rows_f32
+    fn.restype = None
+    fn(_p(Q), _p(K), _p(V), _p(dO), _p(O), _p(dQ), _p(dK), _p(dV), _c_int(N), _c_int(d),
+       _c_float(scale), _c_int(row0), _c_int(stride))
+    return O, dQ, dK, dV
+
+
+def get_threads():
+    try:
+        omp = ctypes.CDLL("libgomp.so.1")
+        omp.omp_get_max_threads.restype = ctypes.c_int
+        return int(omp.omp_get_max_threads())
+    except OSError:
+        return 1

@@ -343,3 +343,69 @@ void oracle_ring_step(const float* Q, const float* K, const float* V,
     }
     free(s);
 }
+
+/* ------------------------------------------------------------------------- */
+/* cpu_baseline sample: forward + backward work of a strided set of query rows */
+/* ------------------------------------------------------------------------- */
+
+/* For query rows row0, row0+stride, ... of ONE head slab [N][d]: the full naive forward of
+ * the row (naive_attention.h:15-58 in fp32, the reference's arithmetic type) followed by
+ * that row's share of the backward in the O(N^2 d) form (dP, dS = P o (dP - D), its dQ row
+ * and its contributions to dK and dV): 14 N d flops per row, i.e. exactly the row's share
+ * of the 4 N^2 d + 10 N^2 d the bench counts.  Threads split the rows and keep private dK/dV
+ * partials (summed at the end).  Used by bench.py to time the CPU path beside the GPU. */
+void oracle_fwdbwd_rows_f32(const float* Q, const float* K, const float* V, const float* dO,
+                            float* O_rows, float* dQ_rows, float* dK, float* dV,
+                            int N, int d, float scale, int row0, int stride)
+{
+    if (scale == 0) scale = 1.0f / sqrtf((float)d);
+    if (stride < 1) stride = 1;
+    const int nrows = row0 < N ? (N - row0 + stride - 1) / stride : 0;
+    const size_t nd = (size_t)N * d;
+    for (size_t t = 0; t < nd; ++t) { dK[t] = 0.0f; dV[t] = 0.0f; }
+#pragma omp parallel
+    {
+        float* p  = (float*)malloc(sizeof(float) * (size_t)(N > 0 ? N : 1));
+        float* aK = (float*)calloc(nd > 0 ? nd : 1, sizeof(float));
+        float* aV = (float*)calloc(nd > 0 ? nd : 1, sizeof(float));
+#pragma omp for schedule(dynamic, 4)
+        for (int t = 0; t < nrows; ++t) {
+            const int i = row0 + t * stride;
+            const float* q = Q + (size_t)i * d;
+            const float* g = dO + (size_t)i * d;
+            float total;
+            (void)softmax_row_ref_order(q, K, N, d, scale, p, &total);
+            for (int j = 0; j < N; ++j) p[j] /= total;
+            float* o = O_rows + (size_t)t * d;
+            for (int c = 0; c < d; ++c) o[c] = 0.0f;
+            for (int j = 0; j < N; ++j) {
+                const float* vr = V + (size_t)j * d;
+                for (int c = 0; c < d; ++c) o[c] += p[j] * vr[c];
+            }
+            float D = 0.0f;
+            for (int c = 0; c < d; ++c) D += g[c] * o[c];
+            float* dq = dQ_rows + (size_t)t * d;
+            for (int c = 0; c < d; ++c) dq[c] = 0.0f;
+            for (int j = 0; j < N; ++j) {
+                const float* vr = V + (size_t)j * d;
+                const float* kr = K + (size_t)j * d;
+                float dp = 0.0f;
+                for (int c = 0; c < d; ++c) dp += g[c] * vr[c];
+                const float ds = p[j] * (dp - D);
+                float* ak = aK + (size_t)j * d;
+                float* av = aV + (size_t)j * d;
+                for (int c = 0; c < d; ++c) {
+                    dq[c] += ds * kr[c];
+                    ak[c] += ds * q[c];
+                    av[c] += p[j] * g[c];
+                }
+            }
+            for (int c = 0; c < d; ++c) dq[c] *= scale;
+        }
+#pragma omp critical
+        {
+            for (size_t t = 0; t < nd; ++t) { dK[t] += aK[t] * scale; dV[t] += aV[t]; }
+        }
+        free(p); free(aK); free(aV);
+    }
+}
