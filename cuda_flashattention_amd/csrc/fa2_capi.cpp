@@ -100,6 +100,7 @@ int fa2_forward(const void* Q, const void* K, const void* V, void* O, float* L,
     fa2::F32Args a{};
     a.Q = (const float*)Q; a.K = (const float*)K; a.V = (const float*)V; a.O = (float*)O; a.L = L;
     a.BH = B * H; a.N = seq_len; a.d = head_dim; a.scale = softmax_scale; a.causal = causal ? 1 : 0;
+    a.Nk = seq_len; a.M = nullptr; a.resume = 0; a.finalize = 1;
     return hip_status(fa2::launch_fwd_f32(a, (hipStream_t)stream));
 }
 
@@ -150,16 +151,27 @@ int fa2_backward_phases(const void* Q, const void* K, const void* V, const void*
 int fa2_forward_step(const void* Q, const void* K, const void* V,
                      void* O, float* L, float* Oacc, float* M,
                      int B, int H, int q_len, int kv_len, int head_dim, float softmax_scale,
-                     int first, int last, void* stream)
+                     int dtype, int first, int last, void* stream)
 {
     if (!Q || !K || !V || !L) return FA2_ERR_NULL_POINTER;
-    if (last && !O) return FA2_ERR_NULL_POINTER;
-    if ((!first || !last) && (!Oacc || !M)) return FA2_ERR_NULL_POINTER;
     int st = check_common(B, H, q_len, head_dim, softmax_scale);
     if (st) return st;
     if (kv_len <= 0) return FA2_ERR_INVALID_SHAPE;
-    st = check_dim(head_dim, FA2_DTYPE_BF16);
+    st = check_dim(head_dim, dtype);
     if (st) return st;
+    if (dtype == FA2_DTYPE_F32) {
+        // fp32: O itself carries the un-normalised accumulator between steps (the reference's
+        // layout); Oacc is ignored.
+        if (!O) return FA2_ERR_NULL_POINTER;
+        if ((!first || !last) && !M) return FA2_ERR_NULL_POINTER;
+        fa2::F32Args a{};
+        a.Q = (const float*)Q; a.K = (const float*)K; a.V = (const float*)V; a.O = (float*)O; a.L = L;
+        a.BH = B * H; a.N = q_len; a.Nk = kv_len; a.d = head_dim; a.scale = softmax_scale; a.causal = 0;
+        a.M = M; a.resume = first ? 0 : 1; a.finalize = last ? 1 : 0;
+        return hip_status(fa2::launch_fwd_f32(a, (hipStream_t)stream));
+    }
+    if (last && !O) return FA2_ERR_NULL_POINTER;
+    if ((!first || !last) && (!Oacc || !M)) return FA2_ERR_NULL_POINTER;
     fa2::FwdArgs a{};
     a.Q = Q; a.K = K; a.V = V; a.O = O; a.L = L; a.Oacc = Oacc; a.M = M;
     a.BH = B * H; a.Nq = q_len; a.Nk = kv_len; a.d = head_dim; a.scale = softmax_scale;

@@ -53,11 +53,12 @@ __global__ void __launch_bounds__(256, 1) fa2_fwd_f32_kernel(F32Args p)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int qi = lane & 31, h = lane >> 5;
     const int N = p.N, d = p.d;
+    const int Nk = p.Nk > 0 ? p.Nk : N;
     const int nrb = (N + 32 * kF32Waves - 1) / (32 * kF32Waves);
     const int head = blockIdx.x / nrb, rb = blockIdx.x % nrb;
     const float* Qh = p.Q + (size_t)head * N * d;
-    const float* Kh = p.K + (size_t)head * N * d;
-    const float* Vh = p.V + (size_t)head * N * d;
+    const float* Kh = p.K + (size_t)head * Nk * d;
+    const float* Vh = p.V + (size_t)head * Nk * d;
 
     const int q0 = rb * 32 * kF32Waves + wave * 32;
     const int qrow = q0 + qi;
@@ -70,21 +71,34 @@ __global__ void __launch_bounds__(256, 1) fa2_fwd_f32_kernel(F32Args p)
         qreg[s] = c < d ? Qh[(size_t)qld * d + c] : 0.0f;
     }
     f32x16 oacc[DT];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.0f;
     float m_run = -INFINITY, l_run = 0.0f;
+    if (p.resume) {
+        const float* Oq = p.O + ((size_t)head * N + qld) * d;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = 32 * dt + acc_row(r, h);
+                oacc[dt][r] = c < d ? Oq[c] : 0.0f;
+            }
+        m_run = p.M[(size_t)head * N + qld];
+        l_run = h == 0 ? p.L[(size_t)head * N + qld] : 0.0f;
+    } else {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.0f;
+    }
 
-    int ntiles = (N + kF32Tile - 1) / kF32Tile;
+    int ntiles = (Nk + kF32Tile - 1) / kF32Tile;
     if (CAUSAL) ntiles = min(ntiles, min(rb * 32 * kF32Waves + 32 * kF32Waves - 1, N - 1) / kF32Tile + 1);
     const float c2 = p.scale * kLog2e;
 
     for (int t = 0; t < ntiles; ++t) {
         const int key0 = t * kF32Tile;
         __syncthreads();
-        stage_tile_f32<DP>(Ks, Kh, key0, N, d);
-        stage_tile_f32<DP>(Vs, Vh, key0, N, d);
+        stage_tile_f32<DP>(Ks, Kh, key0, Nk, d);
+        stage_tile_f32<DP>(Vs, Vh, key0, Nk, d);
         __syncthreads();
         bool active = true;
         if (CAUSAL) active = key0 <= q0 + 31;
@@ -100,7 +114,7 @@ __global__ void __launch_bounds__(256, 1) fa2_fwd_f32_kernel(F32Args p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = key0 + acc_row(r, h);
-            bool dead = key >= N;
+            bool dead = key >= Nk;
             if (CAUSAL) dead = dead || key > qrow;
             if (dead) sacc[r] = -INFINITY;
             mx = fmaxf(mx, sacc[r]);
@@ -130,7 +144,7 @@ __global__ void __launch_bounds__(256, 1) fa2_fwd_f32_kernel(F32Args p)
 
     const float l_tot = half_sum(l_run);
     if (qrow < N) {
-        const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
+        const float inv = !p.finalize ? 1.0f : (l_tot > 0.0f ? 1.0f / l_tot : 0.0f);
         float* Oq = p.O + ((size_t)head * N + qrow) * d;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
@@ -139,7 +153,14 @@ __global__ void __launch_bounds__(256, 1) fa2_fwd_f32_kernel(F32Args p)
                 const int c = 32 * dt + acc_row(r, h);
                 if (c < d) Oq[c] = oacc[dt][r] * inv;
             }
-        if (h == 0) p.L[(size_t)head * N + qrow] = m_run + logf(l_tot);
+        if (h == 0) {
+            if (p.finalize) {
+                p.L[(size_t)head * N + qrow] = m_run + logf(l_tot);
+            } else {
+                p.L[(size_t)head * N + qrow] = l_tot;
+                p.M[(size_t)head * N + qrow] = m_run;
+            }
+        }
     }
 }
 

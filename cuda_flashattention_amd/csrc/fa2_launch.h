@@ -49,6 +49,12 @@ struct F32Args {
     float scale;
     int causal;
     int phases;       // backward only, as BwdArgs::phases
+    // forward only -- resumable step (ring): Nk keys in the resident shard (0 = N), running max
+    // in M, running sum in L and the un-normalised accumulator in O itself between steps,
+    // exactly the reference's state layout (ring_attention_kernel.cu:67-79, :125-137).
+    int Nk;
+    float* M;
+    int resume, finalize;   // plain forward: resume = 0, finalize = 1
 };
 hipError_t launch_fwd_f32(const F32Args& a, hipStream_t stream);
 hipError_t launch_bwd_f32(const F32Args& a, hipStream_t stream);

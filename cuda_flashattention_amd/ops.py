@@ -88,6 +88,6 @@ def forward_step(Q, K, V, O, L, Oacc, M, softmax_scale, first, last, stream=None
                                       O.data_ptr() if O is not None else None, L.data_ptr(),
                                       Oacc.data_ptr() if Oacc is not None else None,
                                       M.data_ptr() if M is not None else None,
-                                      B, H, Nq, Nk, d, float(softmax_scale),
+                                      B, H, Nq, Nk, d, float(softmax_scale), _dtype_code(Q),
                                       1 if first else 0, 1 if last else 0, _stream_ptr(stream))
     check(st, "fa2_forward_step")

@@ -1,0 +1,249 @@
+"""Host-side mirror of the reference's ring-attention interface
+(ring_attention_forward, src/03_flash_attention_v2_ring/common/ring_attention_kernel.cu:143-156;
+init_nccl_comm / ring_exchange_kv, src/util/nccl_utils.h:29-56, :115-142).
+
+One process per GPU, launched by torch.distributed.run.  torch.distributed replaces the
+reference's MPI as the *bootstrap* only (it carries the 128-byte RCCL unique id from rank 0);
+the data path is libfa2_ring_mi355x.so: RCCL send/recv over xGMI on its own stream, event-fenced
+against the FA2 step kernel (include/fa2_ring_mi355x.h).
+
+Two transports share one schedule:
+  * RingContext / ring_attention_forward      -- the native C ABI (RCCL called from C++);
+  * ring_attention_forward_p2p                -- the same relay schedule written over
+    torch.distributed point-to-point ops with a pluggable step function.  With backend "nccl"
+    this is again RCCL over xGMI driving the same HIP step kernel; with "gloo" and a CPU step
+    function supplied by the caller it is how the N > 1 path is exercised without GPUs
+    (tests/test_ring_gloo.py).
+"""
+import ctypes
+import math
+import os
+import time
+
+import torch
+
+from . import _capi
+from ._capi import FA2_DTYPE_BF16, FA2_DTYPE_F32, check
+
+RELAY = 0
+MESH = 1
+_SCHEDULES = {"relay": RELAY, "mesh": MESH, RELAY: RELAY, MESH: MESH}
+
+_vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+# mirrors include/fa2_ring_mi355x.h declaration by declaration
+RING_SIGNATURES = {
+    "fa2_ring_get_unique_id": (_i, [_vp]),
+    "fa2_ring_ctx_create": (_i, [ctypes.POINTER(_vp), _vp, _i, _i]),
+    "fa2_ring_ctx_create_from_comm": (_i, [ctypes.POINTER(_vp), _vp, _i, _i]),
+    "fa2_ring_ctx_destroy": (_i, [_vp]),
+    "fa2_ring_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    "fa2_ring_attention_forward": (_i, [_vp] * 6 + [_i, _i, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp]),
+    "ring_attention_forward": (_i, [_vp] * 5 + [_i, _i, _i, _f, _vp, _i, _i]),
+    "fa2_ring_exchange_kv": (_i, [_vp] * 5 + [_sz, _vp]),
+}
+
+_ring = None
+
+
+def ring_lib():
+    """libfa2_ring_mi355x.so (needs torch imported first so that librccl.so.1 / libamdhip64.so.7
+    resolve to the copies torch already loaded).  Raises if it is missing."""
+    global _ring
+    if _ring is None:
+        _capi.lib()
+        if not os.path.exists(_capi.RING_LIB_PATH):
+            raise ImportError(f"{_capi.RING_LIB_PATH} is missing: `make -C cuda_flashattention_amd/csrc ring`")
+        h = ctypes.CDLL(_capi.RING_LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+        for name, (res, args) in RING_SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        _ring = h
+    return _ring
+
+
+def _dtype_code(t):
+    if t.dtype == torch.bfloat16:
+        return FA2_DTYPE_BF16
+    if t.dtype == torch.float32:
+        return FA2_DTYPE_F32
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def shard_rows(total_seq_len, rank, nranks):
+    """Row range [lo, hi) of rank's contiguous shard; N must divide (04_ring_attention.cu:55-63)."""
+    if total_seq_len % nranks != 0:
+        raise ValueError("seq_len must be divisible by nranks!")
+    n = total_seq_len // nranks
+    return rank * n, (rank + 1) * n
+
+
+def kv_owner(rank, step, nranks):
+    """Owner of the K/V shard rank computes on at `step` (ring_attention_kernel.cu:198)."""
+    return (rank - step + nranks) % nranks
+
+
+class RingContext:
+    """RCCL communicator + comm stream + events for one rank (fa2_ring_ctx).  Collective."""
+
+    def __init__(self, dist=None, rank=0, nranks=1):
+        lib = ring_lib()
+        self.rank, self.nranks = rank, nranks
+        ident = ctypes.create_string_buffer(128)
+        if rank == 0:
+            check(lib.fa2_ring_get_unique_id(ident), "fa2_ring_get_unique_id")
+        if nranks > 1:
+            box = [bytes(ident.raw)]
+            dist.broadcast_object_list(box, src=0)     # the reference's MPI_Bcast (nccl_utils.h:42)
+            ident = ctypes.create_string_buffer(box[0], 128)
+        self._h = _vp()
+        check(lib.fa2_ring_ctx_create(ctypes.byref(self._h), ident, rank, nranks), "fa2_ring_ctx_create")
+        self._ws = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            ring_lib().fa2_ring_ctx_destroy(self._h)
+            self._h = None
+
+    def workspace(self, B, H, n_local, d, dtype_code, schedule, device):
+        need = ring_lib().fa2_ring_workspace_bytes(B, H, n_local, d, dtype_code, self.nranks, schedule)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(max(need, 256), dtype=torch.uint8, device=device)
+        return self._ws
+
+
+def ring_attention_forward(ctx, Q_local, K_local, V_local, softmax_scale=None, schedule="relay",
+                           O_local=None, L_local=None, stream=None):
+    """O_local, L_local for this rank's rows.  Mirrors ring_attention_forward(Q_local, K_local,
+    V_local, O_local, L_local, total_seq_len, local_seq_len, head_dim, scale, comm, rank, nranks);
+    tensors [B,H,N/P,d] (or [N/P,d]).  K_local / V_local are left intact."""
+    if Q_local.dim() == 2:
+        B, H = 1, 1
+        n, d = Q_local.shape
+    else:
+        B, H, n, d = Q_local.shape
+    scale = float(softmax_scale) if softmax_scale is not None else 1.0 / math.sqrt(d)
+    sched = _SCHEDULES[schedule]
+    code = _dtype_code(Q_local)
+    if O_local is None:
+        O_local = torch.empty_like(Q_local)
+    if L_local is None:
+        L_local = torch.empty(Q_local.shape[:-1], dtype=torch.float32, device=Q_local.device)
+    ws = ctx.workspace(B, H, n, d, code, sched, Q_local.device)
+    s = stream if stream is not None else torch.cuda.current_stream()
+    st = ring_lib().fa2_ring_attention_forward(
+        ctx._h, Q_local.data_ptr(), K_local.data_ptr(), V_local.data_ptr(), O_local.data_ptr(),
+        L_local.data_ptr(), B, H, n * ctx.nranks, n, d, scale, code, sched,
+        ws.data_ptr(), ws.numel(), s.cuda_stream)
+    check(st, "fa2_ring_attention_forward")
+    return O_local, L_local
+
+
+# ------------------------------------------------------------------------------------------
+# The relay schedule over torch.distributed point-to-point ops
+# ------------------------------------------------------------------------------------------
+def _gpu_step(Q, K, V, O, L, Oacc, M, scale, first, last):
+    from .ops import forward_step
+    forward_step(Q, K, V, O, L, Oacc, M, scale, first, last)
+
+
+def ring_attention_forward_p2p(dist, Q_local, K_local, V_local, softmax_scale=None, step_fn=None,
+                               group=None):
+    """The reference's schedule (ring_attention_kernel.cu:196-231): for step in 0..P-1 compute on
+    the resident K/V shard while it is sent to rank+1 and the next one is received from rank-1
+    (ring_exchange_kv), then swap.  step_fn(Q, K, V, O, L, Oacc, M, scale, first, last) folds one
+    shard into the running state; the default is the HIP step kernel."""
+    rank, P = dist.get_rank(group), dist.get_world_size(group)
+    d = Q_local.shape[-1]
+    scale = float(softmax_scale) if softmax_scale is not None else 1.0 / math.sqrt(d)
+    step_fn = step_fn or _gpu_step
+    O = torch.empty_like(Q_local)
+    L = torch.empty(Q_local.shape[:-1], dtype=torch.float32, device=Q_local.device)
+    M = torch.empty_like(L)
+    Oacc = torch.empty(Q_local.shape, dtype=torch.float32, device=Q_local.device)
+    nxt, prv = (rank + 1) % P, (rank - 1 + P) % P
+    if group is not None:
+        nxt, prv = dist.get_global_rank(group, nxt), dist.get_global_rank(group, prv)
+    cur_k, cur_v = K_local, V_local
+    spare = [(torch.empty_like(K_local), torch.empty_like(V_local)) for _ in range(min(2, P - 1))]
+    for step in range(P):
+        reqs = []
+        if step < P - 1:
+            rk, rv = spare[step % len(spare)]
+            ops = [dist.P2POp(dist.isend, cur_k, nxt, group), dist.P2POp(dist.irecv, rk, prv, group),
+                   dist.P2POp(dist.isend, cur_v, nxt, group), dist.P2POp(dist.irecv, rv, prv, group)]
+            reqs = dist.batch_isend_irecv(ops)
+        step_fn(Q_local, cur_k, cur_v, O, L, Oacc, M, scale, step == 0, step == P - 1)
+        for r in reqs:
+            r.wait()
+        if step < P - 1:
+            cur_k, cur_v = rk, rv
+    return O, L
+
+
+# ------------------------------------------------------------------------------------------
+# bench.py leg: ring forward at N = 8192 * P, d = 128 (BASELINE configs[3] at P = 8)
+# ------------------------------------------------------------------------------------------
+def bench_ring(dist, rank, world, steps=3, warmup=1, B=1, H=16, n_local=8192, d=128):
+    """Times the ring forward; returns the dict bench.py embeds as "ring" (None when world == 1
+    and the library is absent).  B=1, H=16 is this build's stated choice for the BASELINE ring
+    config, which names only N=65536, d=128."""
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(4321 + rank)
+    mk = lambda: (torch.rand(B, H, n_local, d, device=dev, generator=g) - 0.5).to(torch.bfloat16)
+    Q, K, V = mk(), mk(), mk()
+    scale = 1.0 / math.sqrt(d)
+    N = n_local * world
+    flops = 4.0 * B * H * N * N * d
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def time_it(fn):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt / steps
+
+    out = {"config": {"workload": f"ring FA2 forward bf16, seq-sharded N={N} (N/P={n_local}), d={d}, B={B}, H={H}",
+                      "n_gpus": world}, "unit": "TFLOP/s"}
+    results = {}
+    ctx = None
+    try:
+        ctx = RingContext(dist, rank, world)
+        for name in ("relay", "mesh") if world > 1 else ("relay",):
+            O = torch.empty_like(Q)
+            L = torch.empty(B, H, n_local, dtype=torch.float32, device=dev)
+            sec = time_it(lambda: ring_attention_forward(ctx, Q, K, V, scale, schedule=name, O_local=O, L_local=L))
+            results[f"rccl-native/{name}"] = {"ms": round(sec * 1e3, 4), "tflops": round(flops / sec / 1e12, 2)}
+    except Exception as e:   # report, then try the torch.distributed transport
+        results["rccl-native"] = {"error": repr(e)}
+    if world > 1:
+        try:
+            sec = time_it(lambda: ring_attention_forward_p2p(dist, Q, K, V, scale))
+            results["torch.distributed-nccl/relay"] = {"ms": round(sec * 1e3, 4), "tflops": round(flops / sec / 1e12, 2)}
+        except Exception as e:
+            results["torch.distributed-nccl/relay"] = {"error": repr(e)}
+    if ctx is not None:
+        ctx.close()
+    ok = {k: v for k, v in results.items() if "tflops" in v}
+    out["transports"] = results
+    if ok:
+        best = max(ok, key=lambda k: ok[k]["tflops"])
+        out["value"] = ok[best]["tflops"]
+        out["best"] = best
+        out["pct_mfma_peak"] = round(100.0 * ok[best]["tflops"] / world / 2516.6, 2)
+    return out

@@ -102,16 +102,17 @@ int fa2_backward_phases(const void* Q, const void* K, const void* V, const void*
                         int dtype, int causal, void* workspace, size_t workspace_bytes, void* stream,
                         int phases);
 
-/* One resumable forward step: folds the Nk keys/values of a resident shard into the running
- * state (Oacc fp32 un-normalised, Lrun = running sum l, Mrun = running max in natural
- * units) of Nq local query rows -- the unit of work of ring_attention_forward_kernel
- * (ring_attention_kernel.cu:13-140).  first != 0 starts from (0, 0, -inf) instead of loading
- * the state; last != 0 writes O = Oacc / l (bf16) and L = m + ln l instead of storing it.
- * bf16 only, d in {64,128}. */
+/* One resumable forward step: folds the kv_len keys/values of a resident shard into the running
+ * state of q_len local query rows -- the unit of work of ring_attention_forward_kernel
+ * (ring_attention_kernel.cu:13-140).  State between steps: Mrun = running max (natural units),
+ * L = running sum l, and the un-normalised accumulator -- for bf16 in Oacc (fp32
+ * [B][H][q_len][d]), for fp32 in O itself (Oacc ignored), as the reference keeps it (:125-137).
+ * first != 0 starts from (0, 0, -inf) instead of loading the state; last != 0 writes
+ * O = acc / l and L = m + ln l (:112-124) instead of storing the state.  Non-causal. */
 int fa2_forward_step(const void* Q, const void* K, const void* V,
                      void* O, float* L, float* Oacc, float* M,
                      int B, int H, int q_len, int kv_len, int head_dim, float softmax_scale,
-                     int first, int last, void* stream);
+                     int dtype, int first, int last, void* stream);
 
 /* Element-wise helpers (grid-stride, HBM-bound). */
 int fa2_fill_f32(float* dst, size_t n, float value, void* stream);      /* init_array, cuda_helper.h:60-65 */

@@ -1,0 +1,92 @@
+/*
+ * fa2_ring_mi355x.h -- C ABI of the sequence-sharded ring forward (libfa2_ring_mi355x.so).
+ *
+ * Replaces, for the reference's 03_flash_attention_v2_ring:
+ *   ring_attention_forward                     common/ring_attention_kernel.cu:143-239
+ *   ring_exchange / _multi / ring_exchange_kv  util/nccl_utils.h:115-142
+ *   init_nccl_comm / init_mpi_nccl / cleanup   util/nccl_utils.h:29-103
+ *
+ * One process (or one host thread) per GPU.  The sequence is split into P equal contiguous
+ * shards (04_ring_attention.cu:55-84): Q, O, L and the running softmax state stay put; K/V
+ * shards travel by RCCL ncclSend/ncclRecv grouped per step (as nccl_utils.h:123-131) over xGMI
+ * on a dedicated communication stream, double-buffered against the local FA2 step kernel
+ * (fa2_forward_step) and fenced with HIP events -- there is no device-wide synchronisation
+ * per step (the reference has one, ring_attention_kernel.cu:220).
+ *
+ * Differences from the reference, all deliberate:
+ *   - the bootstrap needs no MPI: rank 0 calls fa2_ring_get_unique_id() and ships the 128
+ *     bytes to the other ranks by whatever the launcher offers (torch.distributed broadcast in
+ *     bench.py; ncclCommInitAll + fa2_ring_ctx_create_from_comm in the single-process C++ CLI);
+ *   - communicator, streams, events live in a context created once, not per call
+ *     (the reference cudaMallocs, creates and leaks streams inside every call, :158-163, :192-194);
+ *   - the caller's K_local / V_local are PRESERVED (the reference receives into them, :225-226);
+ *   - scratch (receive buffers, fp32 accumulator, running max) is caller-provided workspace;
+ *   - two schedules: FA2_RING_RELAY is the reference's neighbour relay (send the resident shard to
+ *     rank+1, receive from rank-1, P-1 times); FA2_RING_MESH keeps the same step order but every
+ *     rank fetches each shard DIRECTLY from its owner in one grouped exchange, which on the
+ *     MI355X full xGMI mesh spreads the traffic over all 7 links instead of relaying over one.
+ *   - errors are status codes (fa2_mi355x.h), RCCL failures are FA2_ERR_RCCL_BASE - ncclResult_t.
+ */
+#ifndef FA2_RING_MI355X_H
+#define FA2_RING_MI355X_H
+
+#include <stddef.h>
+#include "fa2_mi355x.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FA2_RING_UNIQUE_ID_BYTES 128
+
+#define FA2_RING_RELAY 0   /* neighbour relay, the reference's schedule */
+#define FA2_RING_MESH  1   /* owner-direct fetch over the full xGMI mesh */
+
+typedef struct fa2_ring_ctx fa2_ring_ctx;
+
+/* Rank 0: fills 128 bytes to be handed to every rank's fa2_ring_ctx_create
+ * (ncclGetUniqueId; replaces the MPI_Bcast of nccl_utils.h:33-49). */
+int fa2_ring_get_unique_id(void* id_out);
+
+/* Collective over the nranks processes/threads: joins the RCCL communicator on the CURRENT
+ * device and creates the communication stream and events. */
+int fa2_ring_ctx_create(fa2_ring_ctx** out, const void* unique_id, int rank, int nranks);
+
+/* Wraps an already-initialised communicator (an ncclComm_t passed as void*), e.g. one of
+ * ncclCommInitAll's in a single-process multi-GPU program.  The context does not own it. */
+int fa2_ring_ctx_create_from_comm(fa2_ring_ctx** out, void* nccl_comm, int rank, int nranks);
+
+int fa2_ring_ctx_destroy(fa2_ring_ctx* ctx);
+
+/* Bytes of workspace fa2_ring_attention_forward needs per rank. */
+size_t fa2_ring_workspace_bytes(int B, int H, int local_seq_len, int head_dim, int dtype,
+                                int nranks, int schedule);
+
+/* O_local, L_local = rows [rank*local, (rank+1)*local) of softmax(scale Q K^T) V over the whole
+ * sequence of total_seq_len = nranks * local_seq_len.  Tensors [B][H][local_seq_len][d];
+ * dtype FA2_DTYPE_BF16 (d in {64,128}) or FA2_DTYPE_F32 (d <= 128).  Non-causal, like the
+ * reference.  Compute runs on `stream`, exchanges on the context's own stream. */
+int fa2_ring_attention_forward(fa2_ring_ctx* ctx,
+                               const void* Q_local, const void* K_local, const void* V_local,
+                               void* O_local, float* L_local,
+                               int B, int H, int total_seq_len, int local_seq_len, int head_dim,
+                               float softmax_scale, int dtype, int schedule,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
+/* Reference-signature drop-in (ring_attention_kernel.cu:143-156): single head, fp32, `comm` is the
+ * caller's ncclComm_t.  Allocates its scratch per call as the reference does, synchronises the
+ * device before returning, and -- unlike the reference -- leaves K_local / V_local intact. */
+int ring_attention_forward(const float* Q_local, float* K_local, float* V_local,
+                           float* O_local, float* L_local,
+                           int total_seq_len, int local_seq_len, int head_dim, float softmax_scale,
+                           void* comm, int rank, int nranks);
+
+/* The bare exchange primitive (ring_exchange_kv, nccl_utils.h:133-142): one grouped
+ * send-to-next / receive-from-previous of a K and a V buffer of `bytes` bytes each on `stream`. */
+int fa2_ring_exchange_kv(fa2_ring_ctx* ctx, const void* send_k, void* recv_k,
+                         const void* send_v, void* recv_v, size_t bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FA2_RING_MI355X_H */

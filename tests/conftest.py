@@ -29,5 +29,8 @@ def _built():
     import subprocess
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"])
     lib = os.path.join(ROOT, "cuda_flashattention_amd", "lib", "libfa2_mi355x.so")
+    csrc = os.path.join(ROOT, "cuda_flashattention_amd", "csrc")
     if not os.path.exists(lib):
-        subprocess.check_call(["make", "-s", "-j", "8", "-C", os.path.join(ROOT, "cuda_flashattention_amd", "csrc")])
+        subprocess.check_call(["make", "-s", "-j", "8", "-C", csrc])
+    if not os.path.exists(lib.replace("libfa2_mi355x", "libfa2_ring_mi355x")):
+        subprocess.check_call(["make", "-s", "-C", csrc, "ring"])

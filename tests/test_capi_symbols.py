@@ -33,6 +33,19 @@ def test_binding_table_matches_header():
     _capi.lib()
 
 
+def test_ring_header_symbols_exported():
+    names = _declared("fa2_ring_mi355x.h")
+    assert "ring_attention_forward" in names and "fa2_ring_attention_forward" in names
+    out = subprocess.run(["nm", "-D", "--defined-only",
+                          os.path.join(ROOT, "cuda_flashattention_amd", "lib", "libfa2_ring_mi355x.so")],
+                         capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    for n in names:
+        assert n in exported, f"{n} declared in include/fa2_ring_mi355x.h but not exported"
+    from cuda_flashattention_amd import ring
+    assert sorted(ring.RING_SIGNATURES) == names
+
+
 def test_argument_checking_status_codes():
     """Status codes instead of the reference's assert/exit (flash_attention_kernel.cu:317)."""
     from cuda_flashattention_amd import _capi

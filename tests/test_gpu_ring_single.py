@@ -1,0 +1,70 @@
+"""GPU (one device): the native ring library end to end with a 1-rank RCCL communicator --
+library loading next to torch's RCCL, context creation from a unique id, the self
+send/receive exchange primitive, and ring forward == plain forward at P = 1.  P > 1 needs
+several GPUs and is covered by tests/test_ring_gloo.py (schedule) + the driver's scaling run."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def test_ring_single_rank_native():
+    import cuda_flashattention_amd as fa
+    from cuda_flashattention_amd import ring
+    ctx = ring.RingContext(None, 0, 1)
+    try:
+        B, H, n, d = 1, 4, 512, 128
+        g = torch.Generator().manual_seed(1)
+        Q, K, V = ((torch.rand(B, H, n, d, generator=g) - 0.5).bfloat16().cuda() for _ in range(3))
+        for sched in ("relay", "mesh"):
+            O, L = ring.ring_attention_forward(ctx, Q, K, V, schedule=sched)
+            O2, L2 = fa.flash_attention_2_forward(Q, K, V)
+            torch.cuda.synchronize()
+            assert torch.equal(O, O2) and torch.equal(L, L2)
+        # exchange primitive: with one rank, next == prev == self
+        a = torch.arange(4096, dtype=torch.float32, device="cuda")
+        b = a * 2
+        ra, rb = torch.zeros_like(a), torch.zeros_like(b)
+        st = ring.ring_lib().fa2_ring_exchange_kv(ctx._h, a.data_ptr(), ra.data_ptr(), b.data_ptr(),
+                                                  rb.data_ptr(), a.numel() * 4,
+                                                  torch.cuda.current_stream().cuda_stream)
+        assert st == 0
+        torch.cuda.synchronize()
+        assert torch.equal(ra, a) and torch.equal(rb, b)
+    finally:
+        ctx.close()
+
+
+def test_ring_reference_signature_fp32_single_rank(golden):
+    """ring_attention_forward(Q_local, K_local, V_local, O_local, L_local, total, local, d, scale,
+    comm, rank, nranks) with nranks = 1 on the reference's ring data (N=5096, d=64, scale 1)."""
+    import ctypes
+    from cuda_flashattention_amd import ring
+    from oracle import recipes
+    lib = ring.ring_lib()
+    rccl = ctypes.CDLL("librccl.so.1")
+    ident = ctypes.create_string_buffer(128)
+    assert lib.fa2_ring_get_unique_id(ident) == 0
+    comm = ctypes.c_void_p()
+
+    class UID(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+    uid = UID.from_buffer_copy(ident.raw)
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UID, ctypes.c_int]
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    try:
+        g = golden("k5_ring_pattern_rows.npz")
+        N, d = int(g["N"]), int(g["d"])
+        Q, K, V = (torch.from_numpy(x).cuda() for x in recipes.ring_pattern(N, d))
+        K0 = K.clone()
+        O = torch.empty_like(Q)
+        L = torch.empty(N, device="cuda")
+        st = lib.ring_attention_forward(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), L.data_ptr(),
+                                        N, N, d, 1.0, comm, 0, 1)
+        assert st == 0
+        assert torch.equal(K, K0)
+        assert recipes.compare_outputs(recipes.ring_pattern_expected(N, d), O.cpu().numpy(), rtol=5e-3, atol=1.0) == 0
+    finally:
+        rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        rccl.ncclCommDestroy(comm)

@@ -1,0 +1,101 @@
+"""CPU, world_size 2 and 3 over gloo: the ring schedule (who computes on whose shard at which
+step, the double-buffered exchange, the resumable softmax state) end to end, with the oracle's
+ring step (ring_attention_kernel.cu:67-137 restated) standing in for the HIP step kernel.
+Compares against one-shot attention on the gathered sequence, like 04_ring_attention.cu does
+with MPI_Gather + compare_outputs."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.distributed as dist          # noqa: E402
+import torch.multiprocessing as mp        # noqa: E402
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_step(Q, K, V, O, L, Oacc, M, scale, first, last):
+    """step_fn for ring_attention_forward_p2p on CPU fp32 tensors [N/P, d]: the state lives in
+    (O, L, M) exactly as in the reference (O un-normalised until the last step)."""
+    import oracle
+    if first:
+        O.zero_()
+        L.zero_()
+        M.fill_(float("-inf"))
+    oracle.ring_step(Q.numpy(), K.numpy(), V.numpy(), O.numpy(), L.numpy(), M.numpy(), float(scale), last)
+
+
+def _worker(rank, world, port, N, d, scale, pattern, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cuda_flashattention_amd import ring
+        from oracle import recipes
+        if pattern:
+            Q, K, V = recipes.ring_pattern(N, d)
+        else:
+            rng = np.random.default_rng(0)
+            Q, K, V = (rng.uniform(-0.5, 0.5, (N, d)).astype(np.float32) for _ in range(3))
+        lo, hi = ring.shard_rows(N, rank, world)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a[lo:hi]))
+        Kl, Vl = t(K), t(V)
+        K0, V0 = Kl.clone(), Vl.clone()
+        O, L = ring.ring_attention_forward_p2p(dist, t(Q), Kl, Vl, scale, step_fn=_oracle_step)
+        assert torch.equal(Kl, K0) and torch.equal(Vl, V0)          # caller's shards preserved
+        gathered = [torch.empty_like(O) for _ in range(world)]
+        dist.all_gather(gathered, O)                                  # MPI_Gather, rank order = row order
+        gl = [torch.empty_like(L) for _ in range(world)]
+        dist.all_gather(gl, L)
+        if rank == 0:
+            ret["O"] = torch.cat(gathered).numpy()
+            ret["L"] = torch.cat(gl).numpy()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,N,d", [(2, 128, 32), (3, 96, 16), (2, 130, 64)])
+def test_ring_schedule_matches_one_shot(world, N, d):
+    import oracle
+    scale = 1.0 / np.sqrt(d)
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(world, _free_port(), N, d, scale, False, ret), nprocs=world, join=True)
+        O, L = ret["O"], ret["L"]
+    rng = np.random.default_rng(0)
+    Q, K, V = (rng.uniform(-0.5, 0.5, (N, d)).astype(np.float32) for _ in range(3))
+    Or, Lr = oracle.naive_forward_pass(Q, K, V, float(scale))
+    assert np.abs(O - Or).max() < 2e-6
+    assert np.abs(L - Lr).max() < 2e-6
+
+
+def test_ring_reference_pattern_two_ranks():
+    """The reference's own ring test data (create_simple_test_data, scale 1) at a reduced length
+    (N=512 instead of 5096 to stay in CPU seconds), P=2 as run.sh:2, judged with its criterion."""
+    from oracle import recipes
+    N, d, world = 512, 64, 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(world, _free_port(), N, d, 1.0, True, ret), nprocs=world, join=True)
+        O = ret["O"]
+    assert recipes.compare_outputs(recipes.ring_pattern_expected(N, d), O, rtol=5e-3, atol=1.0) == 0
+
+
+def test_shard_helpers():
+    from cuda_flashattention_amd import ring
+    assert ring.shard_rows(5096, 1, 2) == (2548, 5096)
+    with pytest.raises(ValueError):
+        ring.shard_rows(5096, 0, 3)                     # "seq_len must be divisible by nranks!"
+    # every rank sees every shard exactly once, starting with its own (ring_attention_kernel.cu:198)
+    for P in (2, 4, 8):
+        for r in range(P):
+            owners = [ring.kv_owner(r, s, P) for s in range(P)]
+            assert owners[0] == r and sorted(owners) == list(range(P))
