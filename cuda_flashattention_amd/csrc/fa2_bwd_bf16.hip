@@ -230,15 +230,27 @@ __global__ void __launch_bounds__(512, 2) fa2_bwd_dq_kernel(BwdArgs p)
 }
 
 // --------------------------------------------------------------------------- kernel 2: dK, dV
+// Workgroup = 4 waves = 256 keys of one head, ONE wave per SIMD so that each wave may use the
+// whole 512-entry register file: a wave owns 64 keys (two 32-key blocks) and keeps dK^T and dV^T
+// of those keys -- 2 x 2 x (D/32) accumulator tiles = 256 registers at D = 128 -- plus its K
+// fragments resident.  V of the workgroup's 256 keys sits in LDS (read once per tile as the B
+// operand of dP); Q/dO tiles of 32 query rows stream through a double-buffered LDS image and
+// every row/transposed fragment read from it feeds BOTH key blocks (half the LDS traffic per
+// MFMA of a 32-key-per-wave split, and no register spills).
+constexpr int kDkWaves = 4;
+constexpr int kDkKeys = 64 * kDkWaves;      // keys per workgroup
+
 template <int D, bool CAUSAL>
-__global__ void __launch_bounds__(512, 2) fa2_bwd_dkdv_kernel(BwdArgs p)
+__global__ void __launch_bounds__(256, 1) fa2_bwd_dkdv_kernel(BwdArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWB = D * 2;
-    constexpr int TILEB = kDkQ * ROWB;          // bytes per Q (or dO) tile: 32 rows
+    constexpr int VIMG = kDkKeys * ROWB;        // V image of the workgroup's keys
+    constexpr int TILEB = kDkQ * ROWB;          // Q (or dO) tile: 32 rows
     constexpr int BUFB = 2 * TILEB + 256;       // Q tile, dO tile, 32 x (-L/scale), 32 x (-D)
     constexpr int CPR = D / 8;
-    constexpr int NCH = kDkQ * CPR;             // chunks per tile: 512 (D=128) or 256 (D=64)
+    constexpr int NCH = kDkQ * CPR;             // chunks per tile
+    constexpr int CPT = 2 * NCH / 256;          // staged chunks per thread (Q and dO): 4 or 2
     constexpr int KS = D / 16;
     constexpr int DT = D / 32;
 
@@ -249,7 +261,7 @@ __global__ void __launch_bounds__(512, 2) fa2_bwd_dkdv_kernel(BwdArgs p)
     const int h = lane >> 5;
     const int N = p.N;
 
-    const int ncb = (N + kBwdRows - 1) / kBwdRows;
+    const int ncb = (N + kDkKeys - 1) / kDkKeys;
     int head, cb;
     map_block(blockIdx.x, p.BH, ncb, head, cb);     // causal: key block 0 is the heaviest, already first
 
@@ -261,39 +273,52 @@ __global__ void __launch_bounds__(512, 2) fa2_bwd_dkdv_kernel(BwdArgs p)
     const float* Lh = p.L + (size_t)head * N;
     const float* Dh = p.D + (size_t)head * N;
 
-    const int k0 = cb * kBwdRows + wave * 32;       // first key of this wave
-    const int key = k0 + ki;
-    const int kld = key < N ? key : N - 1;
+    const int kw0 = cb * kDkKeys + wave * 64;       // first key of this wave
 
-    // K, V fragments: B operands of S = Q K^T and dP = dO V^T (lane = key column).
-    bf16x8 kf[KS], vf[KS];
+    // K fragments of both key blocks: B operands of S = Q K^T (lane = key column).
+    bf16x8 kf[2][KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        kf[s] = *reinterpret_cast<const bf16x8*>(Kh + (size_t)kld * ROWB + 16 * (2 * s + h));
-        vf[s] = *reinterpret_cast<const bf16x8*>(Vh + (size_t)kld * ROWB + 16 * (2 * s + h));
+    for (int kb = 0; kb < 2; ++kb) {
+        int kr = kw0 + 32 * kb + ki;
+        kr = kr < N ? kr : N - 1;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            kf[kb][s] = *reinterpret_cast<const bf16x8*>(Kh + (size_t)kr * ROWB + 16 * (2 * s + h));
     }
+    // V image: the workgroup's 256 keys, swizzled like every other tile.
+    char* Vimg = smem;
+    for (int c = tid; c < kDkKeys * CPR; c += 256) {
+        const int row = c / CPR, ch = c % CPR;
+        int kr = cb * kDkKeys + row;
+        kr = kr < N ? kr : N - 1;
+        *reinterpret_cast<u32x4*>(Vimg + lds_off<D>(row, ch)) =
+            *reinterpret_cast<const u32x4*>(Vh + (size_t)kr * ROWB + 16 * ch);
+    }
+    char* bufs = smem + VIMG;
 
-    f32x16 dkacc[DT], dvacc[DT];
+    f32x16 dkacc[2][DT], dvacc[2][DT];
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { dkacc[dt][r] = 0.0f; dvacc[dt][r] = 0.0f; }
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dkacc[kb][dt][r] = 0.0f; dvacc[kb][dt][r] = 0.0f; }
 
     const int ntiles = (N + kDkQ - 1) / kDkQ;
     int t0 = 0;
-    if (CAUSAL) t0 = (cb * kBwdRows) / kDkQ;        // earlier query rows see none of these keys
+    if (CAUSAL) t0 = (cb * kDkKeys) / kDkQ;         // earlier query rows see none of these keys
 
     const float c2 = p.scale * kLog2e;
     const float inv_scale = 1.0f / p.scale;
 
-    // staging: thread -> one 16-byte chunk of the Q tile or of the dO tile (D=128: both).
-    constexpr int CPT = 2 * NCH / 512;              // 2 (D=128) or 1 (D=64)
     u32x4 sreg[CPT];
     float rc = 0.0f;                                 // row constant carried by threads 0..63
+    const float* rc_src = tid < 32 ? Lh : Dh;
+    const float rc_mul = tid < 32 ? -inv_scale : -1.0f;
     auto stage_load = [&](int t) {
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
-            const int c = tid + 512 * i;             // 0 .. 2*NCH-1 : first NCH = Q, rest = dO
+            const int c = tid + 256 * i;             // 0 .. 2*NCH-1 : first NCH = Q, rest = dO
             const int which = c / NCH, cc = c % NCH;
             const int row = cc / CPR, ch = cc % CPR;
             int qr = t * kDkQ + row;
@@ -301,22 +326,22 @@ __global__ void __launch_bounds__(512, 2) fa2_bwd_dkdv_kernel(BwdArgs p)
             const char* src = which ? Gh : Qh;
             sreg[i] = *reinterpret_cast<const u32x4*>(src + (size_t)qr * ROWB + 16 * ch);
         }
-        if (tid < 64) {
+        if (tid < 64) {          // raw value only: arithmetic here would wait for the load at once
             int qr = t * kDkQ + (tid & 31);
             qr = qr < N ? qr : N - 1;
-            rc = tid < 32 ? -Lh[qr] * inv_scale : -Dh[qr];
+            rc = rc_src[qr];
         }
     };
     auto stage_write = [&](int buf) {
-        char* b = smem + buf * BUFB;
+        char* b = bufs + buf * BUFB;
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
-            const int c = tid + 512 * i;
+            const int c = tid + 256 * i;
             const int which = c / NCH, cc = c % NCH;
             const int row = cc / CPR, ch = cc % CPR;
             *reinterpret_cast<u32x4*>(b + which * TILEB + lds_off<D>(row, ch)) = sreg[i];
         }
-        if (tid < 64) reinterpret_cast<float*>(b + 2 * TILEB)[tid] = rc;
+        if (tid < 64) reinterpret_cast<float*>(b + 2 * TILEB)[tid] = rc * rc_mul;
     };
 
     if (t0 < ntiles) {
@@ -328,52 +353,70 @@ __global__ void __launch_bounds__(512, 2) fa2_bwd_dkdv_kernel(BwdArgs p)
     const int trq = (lane & 15) >> 2;
     const int trp = lane & 3;
     const int trcb = (lane >> 4) & 1;
+    const char* Vw = Vimg;                          // rows of this wave: 64 * wave + 32 * kb + ki
 
     for (int t = t0; t < ntiles; ++t) {
-        const char* Qt = smem + (t & 1) * BUFB;
+        const char* Qt = bufs + (t & 1) * BUFB;
         const char* Gt = Qt + TILEB;
         const float* rcs = reinterpret_cast<const float*>(Qt + 2 * TILEB);
         const bool more = t + 1 < ntiles;
         if (more) stage_load(t + 1);
 
         const int qb0 = t * kDkQ;
-        bool active = true;
-        if (CAUSAL) active = qb0 + kDkQ - 1 >= k0;     // some query row sees some key of this wave
-
-        if (active) {
+        // (causal: the few leading tiles whose rows all precede this wave's keys are not skipped --
+        // the mask below zeroes them -- so that the loop body stays one straight-line region)
+        {
             // accumulators start from the row constants: S' = Q K^T - L/scale, dP' = dO V^T - D
-            f32x16 sacc, dpacc;
+            f32x16 sacc[2], dpacc[2];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 a = *reinterpret_cast<const f32x4*>(rcs + 8 * g + 4 * h);
                 const f32x4 b = *reinterpret_cast<const f32x4*>(rcs + 32 + 8 * g + 4 * h);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { sacc[4 * g + e] = a[e]; dpacc[4 * g + e] = b[e]; }
+                for (int e = 0; e < 4; ++e) {
+                    sacc[0][4 * g + e] = a[e]; sacc[1][4 * g + e] = a[e];
+                    dpacc[0][4 * g + e] = b[e]; dpacc[1][4 * g + e] = b[e];
+                }
             }
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const int o = lds_off<D>(ki, 2 * s + h);                 // row = query (A operand row = lane & 31)
-                sacc = mfma32(lds_read_frag(Qt, o), kf[s], sacc);        // S'[q][key]
-                dpacc = mfma32(lds_read_frag(Gt, o), vf[s], dpacc);      // dP'[q][key]
+                const int o = lds_off<D>(ki, 2 * s + h);                 // A operand row = query = lane & 31
+                const bf16x8 qa = lds_read_frag(Qt, o);
+                const bf16x8 ga = lds_read_frag(Gt, o);
+                sacc[0] = mfma32(qa, kf[0][s], sacc[0]);                 // S'[q][key]
+                sacc[1] = mfma32(qa, kf[1][s], sacc[1]);
+                const bf16x8 v0 = lds_read_frag(Vw, lds_off<D>(64 * wave + ki, 2 * s + h));
+                const bf16x8 v1 = lds_read_frag(Vw, lds_off<D>(64 * wave + 32 + ki, 2 * s + h));
+                dpacc[0] = mfma32(ga, v0, dpacc[0]);                     // dP'[q][key]
+                dpacc[1] = mfma32(ga, v1, dpacc[1]);
             }
+            // masks as two per-lane bounds on the accumulator's row constant (r&3) + 8(r>>2):
+            // a query row is dead when it lies past the sequence end or (causal) above the key.
             const bool tail = qb0 + kDkQ > N;
             bool diag = false;
-            if (CAUSAL) diag = qb0 < k0 + 31;
+            if (CAUSAL) diag = qb0 < kw0 + 63;
+            const int hi = N - qb0 - 4 * h;
+            bf16x8 pf[2][2], dsf[2][2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float pr = __builtin_amdgcn_exp2f(sacc[r] * c2);
-                if (tail || diag) {
-                    const int q = qb0 + acc_row(r, h);
-                    bool dead = q >= N;
-                    if (CAUSAL) dead = dead || key > q;
-                    if (dead) pr = 0.0f;
+            for (int kb = 0; kb < 2; ++kb) {
+                const int lo = CAUSAL ? (kw0 + 32 * kb + ki) - qb0 - 4 * h : -1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float pr = __builtin_amdgcn_exp2f(sacc[kb][r] * c2);
+                    if (tail || diag) {
+                        constexpr int dummy = 0; (void)dummy;
+                        const int rr = (r & 3) + 8 * (r >> 2);
+                        if (rr >= hi || rr < lo) pr = 0.0f;
+                    }
+                    sacc[kb][r] = pr;                            // P[q][key]
+                    dpacc[kb][r] = pr * dpacc[kb][r];            // dS[q][key]
                 }
-                sacc[r] = pr;                        // P[q][key]
-                dpacc[r] = pr * dpacc[r];            // dS[q][key]
-            }
-            bf16x8 pf[2], dsf[2];
 #pragma unroll
-            for (int sp = 0; sp < 2; ++sp) { pf[sp] = pack_acc(sacc, sp); dsf[sp] = pack_acc(dpacc, sp); }
+                for (int sp = 0; sp < 2; ++sp) {
+                    pf[kb][sp] = pack_acc(sacc[kb], sp);
+                    dsf[kb][sp] = pack_acc(dpacc[kb], sp);
+                }
+            }
 
             // dV^T[dcol][key] += dO^T[dcol][q] P[q][key];  dK^T[dcol][key] += Q^T[dcol][q] dS[q][key]
 #pragma unroll
@@ -395,8 +438,10 @@ __global__ void __launch_bounds__(512, 2) fa2_bwd_dkdv_kernel(BwdArgs p)
                         gT[e] = gp[0][e]; gT[4 + e] = gp[1][e];
                         qT[e] = qp[0][e]; qT[4 + e] = qp[1][e];
                     }
-                    dvacc[dt] = mfma32(gT, pf[sp], dvacc[dt]);
-                    dkacc[dt] = mfma32(qT, dsf[sp], dkacc[dt]);
+                    dvacc[0][dt] = mfma32(gT, pf[0][sp], dvacc[0][dt]);
+                    dvacc[1][dt] = mfma32(gT, pf[1][sp], dvacc[1][dt]);
+                    dkacc[0][dt] = mfma32(qT, dsf[0][sp], dkacc[0][dt]);
+                    dkacc[1][dt] = mfma32(qT, dsf[1][sp], dkacc[1][dt]);
                 }
         }
 
@@ -404,22 +449,26 @@ __global__ void __launch_bounds__(512, 2) fa2_bwd_dkdv_kernel(BwdArgs p)
         __syncthreads();
     }
 
-    if (key < N) {
-        char* dKk = (char*)p.dK + slab + (size_t)key * ROWB;
-        char* dVk = (char*)p.dV + slab + (size_t)key * ROWB;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+    for (int kb = 0; kb < 2; ++kb) {
+        const int key = kw0 + 32 * kb + ki;
+        if (key < N) {
+            char* dKk = (char*)p.dK + slab + (size_t)key * ROWB;
+            char* dVk = (char*)p.dV + slab + (size_t)key * ROWB;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                bf16x4 a, b;
+            for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    a[e] = (__bf16)(dkacc[dt][4 * g + e] * p.scale);
-                    b[e] = (__bf16)dvacc[dt][4 * g + e];
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 a, b;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        a[e] = (__bf16)(dkacc[kb][dt][4 * g + e] * p.scale);
+                        b[e] = (__bf16)dvacc[kb][dt][4 * g + e];
+                    }
+                    *reinterpret_cast<bf16x4*>(dKk + 2 * (32 * dt + 8 * g + 4 * h)) = a;
+                    *reinterpret_cast<bf16x4*>(dVk + 2 * (32 * dt + 8 * g + 4 * h)) = b;
                 }
-                *reinterpret_cast<bf16x4*>(dKk + 2 * (32 * dt + 8 * g + 4 * h)) = a;
-                *reinterpret_cast<bf16x4*>(dVk + 2 * (32 * dt + 8 * g + 4 * h)) = b;
-            }
+        }
     }
 }
 
@@ -437,7 +486,7 @@ static hipError_t launch_bwd_one(const BwdArgs& a, hipStream_t stream)
     }
     const int nb = (a.N + kBwdRows - 1) / kBwdRows;
     constexpr int lds_dq = 2 * 2 * kDqKV * D * 2;
-    constexpr int lds_dk = 2 * (2 * kDkQ * D * 2 + 256);
+    constexpr int lds_dk = kDkKeys * D * 2 + 2 * (2 * kDkQ * D * 2 + 256);
     static bool set_dq[64] = {}, set_dk[64] = {};
     e = ensure_dynamic_lds(fa2_bwd_dq_kernel<D, CAUSAL>, lds_dq, set_dq);
     if (e != hipSuccess) return e;
@@ -449,7 +498,8 @@ static hipError_t launch_bwd_one(const BwdArgs& a, hipStream_t stream)
         if (e != hipSuccess) return e;
     }
     if (a.phases & 4) {
-        hipLaunchKernelGGL((fa2_bwd_dkdv_kernel<D, CAUSAL>), dim3((unsigned)(nb * a.BH)), dim3(512), lds_dk, stream, a);
+        const int ncb = (a.N + kDkKeys - 1) / kDkKeys;
+        hipLaunchKernelGGL((fa2_bwd_dkdv_kernel<D, CAUSAL>), dim3((unsigned)(ncb * a.BH)), dim3(256), lds_dk, stream, a);
         e = hipGetLastError();
     }
     return e;
