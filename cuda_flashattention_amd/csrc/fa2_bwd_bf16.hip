@@ -28,17 +28,23 @@
 // ds_read_b64_tr_b16.  Row constants ride in the accumulators: kernel 2 starts the S chain
 // from -L/scale and the dP chain from -D, so p = exp2(c S') and dS = p dP' need no
 // per-element subtraction (rows are registers there, not lanes).
+#include <type_traits>
+
 #include "fa2_common.h"
 #include "fa2_launch.h"
 
 namespace fa2 {
 
 // --------------------------------------------------------------------------- kernel 0: D
-// 16 lanes per row (16 bytes of dO and of O each per step), 4 rows per wave.
+// 16 lanes per row (16 bytes of dO and of O each per step), 4 rows per wave.  Besides D it
+// writes the two row constants kernel 2 preloads into its accumulators, already transformed:
+// RC[0][row] = -L/scale (so that exp2(c (S - L/scale)) = P) and RC[1][row] = -D.
 template <int D>
 __global__ void __launch_bounds__(256) fa2_bwd_delta_kernel(const __bf16* __restrict__ dO,
                                                             const __bf16* __restrict__ O,
-                                                            float* __restrict__ Dv, size_t rows)
+                                                            const float* __restrict__ L,
+                                                            float* __restrict__ Dv, float* __restrict__ RC,
+                                                            size_t rows, float inv_scale)
 {
     const size_t row = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 4;
     const int sub = threadIdx.x & 15;
@@ -54,7 +60,11 @@ __global__ void __launch_bounds__(256) fa2_bwd_delta_kernel(const __bf16* __rest
     }
 #pragma unroll
     for (int off = 8; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 16);
-    if (row < rows && sub == 0) Dv[row] = acc;
+    if (row < rows && sub == 0) {
+        Dv[row] = acc;
+        RC[row] = -L[row] * inv_scale;
+        RC[rows + row] = -acc;
+    }
 }
 
 // --------------------------------------------------------------------------- kernel 1: dQ
@@ -232,25 +242,34 @@ __global__ void __launch_bounds__(512, 2) fa2_bwd_dq_kernel(BwdArgs p)
 // --------------------------------------------------------------------------- kernel 2: dK, dV
 // Workgroup = 4 waves = 256 keys of one head, ONE wave per SIMD so that each wave may use the
 // whole 512-entry register file: a wave owns 64 keys (two 32-key blocks) and keeps dK^T and dV^T
-// of those keys -- 2 x 2 x (D/32) accumulator tiles = 256 registers at D = 128 -- plus its K
-// fragments resident.  V of the workgroup's 256 keys sits in LDS (read once per tile as the B
-// operand of dP); Q/dO tiles of 32 query rows stream through a double-buffered LDS image and
-// every row/transposed fragment read from it feeds BOTH key blocks (half the LDS traffic per
-// MFMA of a 32-key-per-wave split, and no register spills).
+// of those keys -- 2 x 2 x (D/32) accumulator tiles = 256 registers at D = 128, pinned to AGPRs
+// (mfma32_acc) -- plus its K fragments resident in VGPRs.  V of the workgroup's 256 keys sits in
+// LDS (read once per tile as the B operand of dP); Q/dO tiles of 32 query rows stream through a
+// double-buffered LDS image and every row/transposed fragment read from it feeds BOTH key
+// blocks.  At one wave per SIMD nothing hides a stall, so:
+//   * tiles arrive by LDS-DMA (global_load_lds, 16 B per lane, source address pre-swizzled so the
+//     linear LDS write produces the swizzled image): no staging registers, no ds_write, and the
+//     only vector-memory waits in the loop are the ones in front of the per-tile barrier;
+//   * the row constants come pre-transformed from kernel 0 and are DMA'd too;
+//   * fragment reads are software-pipelined one k-step ahead of the MFMAs that use them;
+//   * the tile loop is unrolled by two so every LDS address is a loop-invariant register plus
+//     an immediate.
 constexpr int kDkWaves = 4;
 constexpr int kDkKeys = 64 * kDkWaves;      // keys per workgroup
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int D, bool CAUSAL>
 __global__ void __launch_bounds__(256, 1) fa2_bwd_dkdv_kernel(BwdArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWB = D * 2;
-    constexpr int VIMG = kDkKeys * ROWB;        // V image of the workgroup's keys
     constexpr int TILEB = kDkQ * ROWB;          // Q (or dO) tile: 32 rows
     constexpr int BUFB = 2 * TILEB + 256;       // Q tile, dO tile, 32 x (-L/scale), 32 x (-D)
-    constexpr int CPR = D / 8;
-    constexpr int NCH = kDkQ * CPR;             // chunks per tile
-    constexpr int CPT = 2 * NCH / 256;          // staged chunks per thread (Q and dO): 4 or 2
+    constexpr int CPR = D / 8;                  // 16-byte chunks per row
+    constexpr int RPI = 64 / CPR;               // rows one DMA wave-instruction covers (1 KiB)
+    constexpr int NINS = kDkQ / RPI;            // DMA instructions per tensor per tile: 8 or 4
     constexpr int KS = D / 16;
     constexpr int DT = D / 32;
 
@@ -270,10 +289,12 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dkdv_kernel(BwdArgs p)
     const char* Kh = (const char*)p.K + slab;
     const char* Vh = (const char*)p.V + slab;
     const char* Gh = (const char*)p.dO + slab;
-    const float* Lh = p.L + (size_t)head * N;
-    const float* Dh = p.D + (size_t)head * N;
+    const size_t rc_plane = (size_t)p.BH * N;
 
     const int kw0 = cb * kDkKeys + wave * 64;       // first key of this wave
+
+    char* const bufs = smem;                         // [2][Q tile | dO tile | row constants]
+    char* const Vimg = smem + 2 * BUFB;              // after them: every read offset fits a 16-bit immediate
 
     // K fragments of both key blocks: B operands of S = Q K^T (lane = key column).
     bf16x8 kf[2][KS];
@@ -286,7 +307,6 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dkdv_kernel(BwdArgs p)
             kf[kb][s] = *reinterpret_cast<const bf16x8*>(Kh + (size_t)kr * ROWB + 16 * (2 * s + h));
     }
     // V image: the workgroup's 256 keys, swizzled like every other tile.
-    char* Vimg = smem;
     for (int c = tid; c < kDkKeys * CPR; c += 256) {
         const int row = c / CPR, ch = c % CPR;
         int kr = cb * kDkKeys + row;
@@ -294,7 +314,6 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dkdv_kernel(BwdArgs p)
         *reinterpret_cast<u32x4*>(Vimg + lds_off<D>(row, ch)) =
             *reinterpret_cast<const u32x4*>(Vh + (size_t)kr * ROWB + 16 * ch);
     }
-    char* bufs = smem + VIMG;
 
     f32x16 dkacc[2][DT], dvacc[2][DT];
 #pragma unroll
@@ -307,148 +326,181 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dkdv_kernel(BwdArgs p)
     const int ntiles = (N + kDkQ - 1) / kDkQ;
     int t0 = 0;
     if (CAUSAL) t0 = (cb * kDkKeys) / kDkQ;         // earlier query rows see none of these keys
+    // Always whole pairs of tiles (the loop is unrolled by two and must not branch around the
+    // second tile: a branch there makes hipcc shuttle the AGPR-pinned accumulators through
+    // copies).  An odd count is padded with one tile past the sequence end: all rows masked.
+    const int tend = t0 + ((ntiles - t0 + 1) & ~1);
 
     const float c2 = p.scale * kLog2e;
-    const float inv_scale = 1.0f / p.scale;
 
-    u32x4 sreg[CPT];
-    float rc = 0.0f;                                 // row constant carried by threads 0..63
-    const float* rc_src = tid < 32 ? Lh : Dh;
-    const float rc_mul = tid < 32 ? -inv_scale : -1.0f;
-    auto stage_load = [&](int t) {
-#pragma unroll
-        for (int i = 0; i < CPT; ++i) {
-            const int c = tid + 256 * i;             // 0 .. 2*NCH-1 : first NCH = Q, rest = dO
-            const int which = c / NCH, cc = c % NCH;
-            const int row = cc / CPR, ch = cc % CPR;
-            int qr = t * kDkQ + row;
-            qr = qr < N ? qr : N - 1;
-            const char* src = which ? Gh : Qh;
-            sreg[i] = *reinterpret_cast<const u32x4*>(src + (size_t)qr * ROWB + 16 * ch);
-        }
-        if (tid < 64) {          // raw value only: arithmetic here would wait for the load at once
-            int qr = t * kDkQ + (tid & 31);
-            qr = qr < N ? qr : N - 1;
-            rc = rc_src[qr];
-        }
-    };
-    auto stage_write = [&](int buf) {
+    // ---- LDS-DMA staging.  Wave w issues pieces w, w+4, ... of the 2*NINS pieces of a tile; a
+    // piece is RPI rows = 1 KiB written linearly, lane l -> row l / CPR, slot l % CPR; the slot
+    // must hold chunk (slot ^ f(row)), f being lds_off's swizzle: so the SOURCE address is
+    // permuted, the LDS side stays linear (fa2_common.h: lds_off is an involution in ch).
+    // Wave w's pieces are w and w + 4 of Q and of dO: the swizzle term is the same for all of them
+    // (it depends on the row modulo 16 only), so ONE per-lane byte offset (voffset) serves every
+    // DMA of the wave; the tile/piece part of the address is wave-uniform (soffset) and the slab
+    // is described by a buffer resource whose range check turns rows past the end of the
+    // sequence into zeros -- no clamping arithmetic, no 64-bit per-lane pointers.
+    const int drow = lane / CPR;
+    const int dslot = lane % CPR;
+    const int prow = wave * RPI + drow;                                   // row inside the tile (first piece)
+    const int doff = drow * ROWB + 16 * ((lds_off<D>(prow, dslot) - ROWB * prow) >> 4);
+    const auto q_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Qh, 0, N * ROWB, 0x00020000);
+    const auto g_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Gh, 0, N * ROWB, 0x00020000);
+    const auto rc_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.RC, 0, (int)(2 * rc_plane * 4), 0x00020000);
+    const int rcoff = (int)(((lane < 32 ? 0 : rc_plane) + (size_t)head * N + (lane & 31)) * 4);
+    auto stage = [&](int t, int buf) {
         char* b = bufs + buf * BUFB;
 #pragma unroll
-        for (int i = 0; i < CPT; ++i) {
-            const int c = tid + 256 * i;
-            const int which = c / NCH, cc = c % NCH;
-            const int row = cc / CPR, ch = cc % CPR;
-            *reinterpret_cast<u32x4*>(b + which * TILEB + lds_off<D>(row, ch)) = sreg[i];
+        for (int j = wave; j < 2 * NINS; j += kDkWaves) {
+            const int which = j / NINS, piece = j % NINS;
+            const int soff = (t * kDkQ + piece * RPI) * ROWB;             // wave-uniform
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(which ? g_rsrc : q_rsrc, (lptr_t)(b + which * TILEB + piece * 1024),
+                                                     16, doff, soff, 0, 0);
         }
-        if (tid < 64) reinterpret_cast<float*>(b + 2 * TILEB)[tid] = rc * rc_mul;
+        if (wave == 0)                               // 64 row constants: lanes 0-31 -L/scale, 32-63 -D
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rc_rsrc, (lptr_t)(b + 2 * TILEB), 4, rcoff, t * kDkQ * 4, 0, 0);
     };
 
-    if (t0 < ntiles) {
-        stage_load(t0);
-        stage_write(t0 & 1);
-    }
+    if (t0 < tend) stage(t0, 0);                     // tile t lives in buffer (t - t0) & 1
     __syncthreads();
 
+    // ---- loop-invariant per-lane LDS offsets
     const int trq = (lane & 15) >> 2;
     const int trp = lane & 3;
     const int trcb = (lane >> 4) & 1;
-    const char* Vw = Vimg;                          // rows of this wave: 64 * wave + 32 * kb + ki
+    int roff[KS], toff[DT][2];
+    const char* Vw = smem + 2 * BUFB + 64 * wave * ROWB;          // this wave's 64 V rows (same swizzle phase as row ki)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        roff[s] = lds_off<D>(ki, 2 * s + h);                          // A-operand row = query = lane & 31
+    }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+            toff[dt][jj] = lds_off<D>(8 * jj + 4 * h + trq, 4 * dt + 2 * trcb + (trp >> 1)) + 8 * (trp & 1);   // +16 rows: sp = 1
 
-    for (int t = t0; t < ntiles; ++t) {
-        const char* Qt = bufs + (t & 1) * BUFB;
+    auto tile = [&](auto BUF, int t) {
+        constexpr int buf = decltype(BUF)::value;
+        const char* Qt = smem + buf * BUFB;
         const char* Gt = Qt + TILEB;
         const float* rcs = reinterpret_cast<const float*>(Qt + 2 * TILEB);
-        const bool more = t + 1 < ntiles;
-        if (more) stage_load(t + 1);
+        if (t + 1 < tend) stage(t + 1, buf ^ 1);
 
         const int qb0 = t * kDkQ;
-        // (causal: the few leading tiles whose rows all precede this wave's keys are not skipped --
-        // the mask below zeroes them -- so that the loop body stays one straight-line region)
-        {
-            // accumulators start from the row constants: S' = Q K^T - L/scale, dP' = dO V^T - D
-            f32x16 sacc[2], dpacc[2];
+        // accumulators start from the row constants: S' = Q K^T - L/scale, dP' = dO V^T - D
+        f32x16 sacc[2], dpacc[2];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(rcs + 8 * g + 4 * h);
-                const f32x4 b = *reinterpret_cast<const f32x4*>(rcs + 32 + 8 * g + 4 * h);
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(rcs + 8 * g + 4 * h);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(rcs + 32 + 8 * g + 4 * h);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    sacc[0][4 * g + e] = a[e]; sacc[1][4 * g + e] = a[e];
-                    dpacc[0][4 * g + e] = b[e]; dpacc[1][4 * g + e] = b[e];
-                }
+            for (int e = 0; e < 4; ++e) {
+                sacc[0][4 * g + e] = a[e]; sacc[1][4 * g + e] = a[e];
+                dpacc[0][4 * g + e] = b[e]; dpacc[1][4 * g + e] = b[e];
             }
+        }
+        // S' and dP', fragments read one k-step ahead
+        bf16x8 qa = lds_read_frag(Qt, roff[0]), ga = lds_read_frag(Gt, roff[0]);
+        bf16x8 v0 = lds_read_frag(Vw, roff[0]), v1 = lds_read_frag(Vw, roff[0] + 32 * ROWB);
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const int o = lds_off<D>(ki, 2 * s + h);                 // A operand row = query = lane & 31
-                const bf16x8 qa = lds_read_frag(Qt, o);
-                const bf16x8 ga = lds_read_frag(Gt, o);
-                sacc[0] = mfma32(qa, kf[0][s], sacc[0]);                 // S'[q][key]
-                sacc[1] = mfma32(qa, kf[1][s], sacc[1]);
-                const bf16x8 v0 = lds_read_frag(Vw, lds_off<D>(64 * wave + ki, 2 * s + h));
-                const bf16x8 v1 = lds_read_frag(Vw, lds_off<D>(64 * wave + 32 + ki, 2 * s + h));
-                dpacc[0] = mfma32(ga, v0, dpacc[0]);                     // dP'[q][key]
-                dpacc[1] = mfma32(ga, v1, dpacc[1]);
+        for (int s = 0; s < KS; ++s) {
+            bf16x8 qn = qa, gn = ga, v0n = v0, v1n = v1;
+            if (s + 1 < KS) {
+                qn = lds_read_frag(Qt, roff[s + 1]);
+                gn = lds_read_frag(Gt, roff[s + 1]);
+                v0n = lds_read_frag(Vw, roff[s + 1]);
+                v1n = lds_read_frag(Vw, roff[s + 1] + 32 * ROWB);
             }
-            // masks as two per-lane bounds on the accumulator's row constant (r&3) + 8(r>>2):
-            // a query row is dead when it lies past the sequence end or (causal) above the key.
-            const bool tail = qb0 + kDkQ > N;
-            bool diag = false;
-            if (CAUSAL) diag = qb0 < kw0 + 63;
-            const int hi = N - qb0 - 4 * h;
-            bf16x8 pf[2][2], dsf[2][2];
+            sacc[0] = mfma32(qa, kf[0][s], sacc[0]);                 // S'[q][key]
+            sacc[1] = mfma32(qa, kf[1][s], sacc[1]);
+            dpacc[0] = mfma32(ga, v0, dpacc[0]);                     // dP'[q][key]
+            dpacc[1] = mfma32(ga, v1, dpacc[1]);
+            qa = qn; ga = gn; v0 = v0n; v1 = v1n;
+        }
+
+        // first transposed fragments go out before the softmax arithmetic (asm form: see
+        // lds_read_tr_asm -- the builtin would wait for the DMA issued at the top of the tile)
+        constexpr int QB = buf * BUFB, GB = buf * BUFB + TILEB, SPB = 16 * ROWB;
+        const uint32_t lbase = (uint32_t)(uintptr_t)smem;
+        bf16x4 gp0 = lds_read_tr_asm<GB>(lbase + toff[0][0]), gp1 = lds_read_tr_asm<GB>(lbase + toff[0][1]);
+        bf16x4 qp0 = lds_read_tr_asm<QB>(lbase + toff[0][0]), qp1 = lds_read_tr_asm<QB>(lbase + toff[0][1]);
+
+        // masks as two per-lane bounds on the accumulator's row constant (r&3) + 8(r>>2): a query
+        // row is dead when it lies past the sequence end or (causal) above the key.
+        const bool tail = qb0 + kDkQ > N;
+        bool diag = false;
+        if (CAUSAL) diag = qb0 < kw0 + 63;
+        const int hi = N - qb0 - 4 * h;
+        bf16x8 pf[2][2], dsf[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[kb][r] = __builtin_amdgcn_exp2f(sacc[kb][r] * c2);   // P[q][key]
+        if (tail || diag) {          // wave-uniform and rare: a branch, not 64 selects per tile
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 const int lo = CAUSAL ? (kw0 + 32 * kb + ki) - qb0 - 4 * h : -1;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float pr = __builtin_amdgcn_exp2f(sacc[kb][r] * c2);
-                    if (tail || diag) {
-                        constexpr int dummy = 0; (void)dummy;
-                        const int rr = (r & 3) + 8 * (r >> 2);
-                        if (rr >= hi || rr < lo) pr = 0.0f;
-                    }
-                    sacc[kb][r] = pr;                            // P[q][key]
-                    dpacc[kb][r] = pr * dpacc[kb][r];            // dS[q][key]
-                }
-#pragma unroll
-                for (int sp = 0; sp < 2; ++sp) {
-                    pf[kb][sp] = pack_acc(sacc[kb], sp);
-                    dsf[kb][sp] = pack_acc(dpacc[kb], sp);
+                    const int rr = (r & 3) + 8 * (r >> 2);
+                    if (rr >= hi || rr < lo) sacc[kb][r] = 0.0f;
                 }
             }
-
-            // dV^T[dcol][key] += dO^T[dcol][q] P[q][key];  dK^T[dcol][key] += Q^T[dcol][q] dS[q][key]
+        }
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
+        for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-                for (int sp = 0; sp < 2; ++sp) {
-                    bf16x4 gp[2], qp[2];
+            for (int r = 0; r < 16; ++r) dpacc[kb][r] = sacc[kb][r] * dpacc[kb][r];                 // dS[q][key]
 #pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) {
-                        const int row = 16 * sp + 8 * jj + 4 * h + trq;
-                        const int ch = 4 * dt + 2 * trcb + (trp >> 1);
-                        const int o = lds_off<D>(row, ch) + 8 * (trp & 1);
-                        gp[jj] = lds_read_tr(Gt, o);
-                        qp[jj] = lds_read_tr(Qt, o);
-                    }
-                    bf16x8 gT, qT;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        gT[e] = gp[0][e]; gT[4 + e] = gp[1][e];
-                        qT[e] = qp[0][e]; qT[4 + e] = qp[1][e];
-                    }
-                    dvacc[0][dt] = mfma32(gT, pf[0][sp], dvacc[0][dt]);
-                    dvacc[1][dt] = mfma32(gT, pf[1][sp], dvacc[1][dt]);
-                    dkacc[0][dt] = mfma32(qT, dsf[0][sp], dkacc[0][dt]);
-                    dkacc[1][dt] = mfma32(qT, dsf[1][sp], dkacc[1][dt]);
-                }
+            for (int sp = 0; sp < 2; ++sp) {
+                pf[kb][sp] = pack_acc(sacc[kb], sp);
+                dsf[kb][sp] = pack_acc(dpacc[kb], sp);
+            }
         }
 
-        if (more) stage_write((t + 1) & 1);
-        __syncthreads();
+        // dV^T[dcol][key] += dO^T[dcol][q] P[q][key];  dK^T[dcol][key] += Q^T[dcol][q] dS[q][key]
+        // Group g = (dt, sp): four tr reads one group ahead of the four MFMAs that use them.
+#pragma unroll
+        for (int g = 0; g < 2 * DT; ++g) {
+            const int dt = g >> 1, sp = g & 1;
+            bf16x4 gn0 = gp0, gn1 = gp1, qn0 = qp0, qn1 = qp1;
+            if (g + 1 < 2 * DT) {
+                const int dtn = (g + 1) >> 1;
+                if ((g + 1) & 1) {
+                    gn0 = lds_read_tr_asm<GB + SPB>(lbase + toff[dtn][0]); gn1 = lds_read_tr_asm<GB + SPB>(lbase + toff[dtn][1]);
+                    qn0 = lds_read_tr_asm<QB + SPB>(lbase + toff[dtn][0]); qn1 = lds_read_tr_asm<QB + SPB>(lbase + toff[dtn][1]);
+                } else {
+                    gn0 = lds_read_tr_asm<GB>(lbase + toff[dtn][0]); gn1 = lds_read_tr_asm<GB>(lbase + toff[dtn][1]);
+                    qn0 = lds_read_tr_asm<QB>(lbase + toff[dtn][0]); qn1 = lds_read_tr_asm<QB>(lbase + toff[dtn][1]);
+                }
+                lds_tr_wait<4>(gp0, gp1, qp0, qp1);      // this group's four landed, next group's in flight
+            } else {
+                lds_tr_wait<0>(gp0, gp1, qp0, qp1);
+            }
+            bf16x8 gT, qT;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                gT[e] = gp0[e]; gT[4 + e] = gp1[e];
+                qT[e] = qp0[e]; qT[4 + e] = qp1[e];
+            }
+            mfma32_acc(dvacc[0][dt], gT, pf[0][sp]);
+            mfma32_acc(dvacc[1][dt], gT, pf[1][sp]);
+            mfma32_acc(dkacc[0][dt], qT, dsf[0][sp]);
+            mfma32_acc(dkacc[1][dt], qT, dsf[1][sp]);
+            gp0 = gn0; gp1 = gn1; qp0 = qn0; qp1 = qn1;
+        }
+        __syncthreads();     // drains this wave's DMA (vmcnt) and hands the buffers over
+    };
+
+    for (int t = t0; t < tend; t += 2) {
+        tile(std::integral_constant<int, 0>{}, t);
+        tile(std::integral_constant<int, 1>{}, t + 1);
     }
 
+    mfma_acc_settle();
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
         const int key = kw0 + 32 * kb + ki;
@@ -480,7 +532,7 @@ static hipError_t launch_bwd_one(const BwdArgs& a, hipStream_t stream)
     hipError_t e = hipSuccess;
     if (a.phases & 1) {
         hipLaunchKernelGGL((fa2_bwd_delta_kernel<D>), dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0,
-                           stream, (const __bf16*)a.dO, (const __bf16*)a.O, a.D, rows);
+                           stream, (const __bf16*)a.dO, (const __bf16*)a.O, a.L, a.D, a.RC, rows, 1.0f / a.scale);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }

@@ -108,7 +108,8 @@ size_t fa2_backward_workspace_bytes(int B, int H, int seq_len, int head_dim, int
 {
     (void)head_dim; (void)dtype;
     if (B <= 0 || H <= 0 || seq_len <= 0) return 0;
-    return align256((size_t)B * H * seq_len * sizeof(float));   // D = rowsum(dO o O)
+    // D = rowsum(dO o O), then the dK/dV kernel's two row-constant planes (-L/scale, -D)
+    return 3 * align256((size_t)B * H * seq_len * sizeof(float));
 }
 
 int fa2_backward(const void* Q, const void* K, const void* V, const void* O, const float* L,
@@ -137,6 +138,7 @@ int fa2_backward_phases(const void* Q, const void* K, const void* V, const void*
         fa2::BwdArgs a{};
         a.Q = Q; a.K = K; a.V = V; a.O = O; a.dO = dO; a.L = L; a.dQ = dQ; a.dK = dK; a.dV = dV;
         a.D = (float*)workspace; a.BH = B * H; a.N = seq_len; a.d = head_dim;
+        a.RC = (float*)((char*)workspace + align256((size_t)B * H * seq_len * sizeof(float)));
         a.scale = softmax_scale; a.causal = causal ? 1 : 0; a.phases = phases & 7;
         return hip_status(fa2::launch_bwd_bf16(a, (hipStream_t)stream));
     }

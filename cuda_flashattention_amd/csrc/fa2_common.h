@@ -62,9 +62,45 @@ __device__ __forceinline__ bf16x4 lds_read_tr(const char* base, int byte_off)
         (lds_bf16x4*)(uintptr_t)(uint32_t)(uintptr_t)(base + byte_off));
 }
 
+// The same read issued from inline asm, for loops that keep an LDS-DMA (buffer_load ... lds) in
+// flight: hipcc puts `s_waitcnt vmcnt(0)` in front of the tr-read BUILTIN whenever a DMA is
+// pending (it cannot tell the two apart), which exposes the whole DMA latency.  The asm form is
+// invisible to that logic; in exchange its completion must be waited for by hand with
+// lds_tr_wait<N>() naming every destination (so no compiler copy can run ahead of the data).
+// `addr` is the lane's LDS byte address, IMM a compile-time byte offset (< 65536).
+template <int IMM>
+__device__ __forceinline__ bf16x4 lds_read_tr_asm(uint32_t addr)
+{
+    bf16x4 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(IMM));
+    return r;
+}
+// Waits until at most N LDS operations of this wave are outstanding (they return in order).
+template <int N>
+__device__ __forceinline__ void lds_tr_wait(bf16x4& a, bf16x4& b, bf16x4& c, bf16x4& d)
+{
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(N));
+}
+
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c)
 {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// Accumulate into a tile that must live in the accumulator half of the register file.  In the
+// one-wave-per-SIMD kernels the long-lived output accumulators (256 registers) are pinned to
+// AGPRs this way, which leaves the 256 architectural VGPRs to the operands and to the
+// short-lived S / dP tiles that the VALU has to read (hipcc otherwise parks operands in AGPRs
+// and copies them back every iteration).  The asm is opaque to hipcc's hazard recogniser:
+// `s_nop 1` covers a VALU-written operand, and whoever reads the tile with non-MFMA code must
+// first execute mfma_acc_settle().
+__device__ __forceinline__ void mfma32_acc(f32x16& c, bf16x8 a, bf16x8 b)
+{
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_acc_settle()
+{
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 }
 
 // Value held by the same lane index in the OTHER 32-lane half of the wave.

@@ -33,6 +33,7 @@ struct BwdArgs {
     const float* L;   // [BH][N] natural-log LSE from the forward
     void* dQ; void* dK; void* dV;   // bf16
     float* D;         // [BH][N] workspace: rowsum(dO o O)
+    float* RC;        // [2][BH][N] workspace: -L/scale and -D, the row constants of the dK/dV kernel
     int BH, N, d;
     float scale;
     int causal;

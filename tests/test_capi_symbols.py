@@ -58,7 +58,7 @@ def test_argument_checking_status_codes():
     assert lib.fa2_forward(one, one, one, one, one, 1, 1, 128, 64, -1.0, 0, 0, None) == -2
     assert lib.fa2_forward(one, one, one, one, one, 1, 1, 128, 64, 0.125, 7, 0, None) == -4
     assert lib.fa2_backward(*([one] * 9), 1, 1, 128, 64, 0.125, 0, 0, None, 0, None) == -5
-    assert lib.fa2_backward_workspace_bytes(4, 16, 8192, 128, 0) == 4 * 16 * 8192 * 4
+    assert lib.fa2_backward_workspace_bytes(4, 16, 8192, 128, 0) == 3 * 4 * 16 * 8192 * 4
     assert b"head_dim" in lib.fa2_status_string(-3)
 
 
