@@ -492,6 +492,9 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dkdv_kernel(BwdArgs p)
             mfma32_acc(dkacc[1][dt], qT, dsf[1][sp]);
             gp0 = gn0; gp1 = gn1; qp0 = qn0; qp1 = qn1;
         }
+        // hipcc may copy a pinned accumulator register (v_accvgpr_mov at the loop back-edge) without
+        // knowing an MFMA is still writing it: let the last MFMAs of the tile retire first.
+        mfma_acc_settle();
         __syncthreads();     // drains this wave's DMA (vmcnt) and hands the buffers over
     };
 

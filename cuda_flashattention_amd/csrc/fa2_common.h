@@ -82,6 +82,12 @@ __device__ __forceinline__ void lds_tr_wait(bf16x4& a, bf16x4& b, bf16x4& c, bf1
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(N));
 }
 
+template <int N>
+__device__ __forceinline__ void lds_tr_wait2(bf16x4& a, bf16x4& b)
+{
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "i"(N));
+}
+
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c)
 {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
