@@ -9,7 +9,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfa2_mi355x.so")
+# FA2_LIB_PATH: load another build of the SAME library (A/B runs of kernel variants); never a fallback.
+LIB_PATH = os.environ.get("FA2_LIB_PATH") or os.path.join(_HERE, "lib", "libfa2_mi355x.so")
 RING_LIB_PATH = os.path.join(_HERE, "lib", "libfa2_ring_mi355x.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "fa2_mi355x.h")
 

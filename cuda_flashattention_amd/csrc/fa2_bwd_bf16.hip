@@ -68,20 +68,38 @@ __global__ void __launch_bounds__(256) fa2_bwd_delta_kernel(const __bf16* __rest
 }
 
 // --------------------------------------------------------------------------- kernel 1: dQ
-constexpr int kBwdRows = 256;   // query rows (kernel 1) / keys (kernel 2) per workgroup
+// Workgroup = 4 waves = 256 query rows of one head, ONE wave per SIMD; a wave owns 64 rows (two
+// 32-row blocks).  Everything long-lived sits in the accumulator half of the register file as
+// literal AGPR ranges owned by asm (fa2_common.h: acc_*): the dQ^T accumulators
+// (2 x D/32 tiles), and the resident Q and dO fragments, which the S^T and dP^T products take
+// straight from AGPRs as their B operand (mfma_bagpr).  The architectural VGPRs are left to the
+// S^T/dP^T tiles of a 64-key tile, the packed dS and the streamed fragments.  K/V tiles (64 keys)
+// arrive by LDS-DMA into a double-buffered swizzled image; every K/V row fragment and every K^T
+// transposed fragment read from LDS feeds both row blocks.
+constexpr int kBwdRows = 256;   // query rows per workgroup (kernel 1)
+constexpr int kDqWaves = 4;
 constexpr int kDqKV = 64;       // keys per streamed tile in kernel 1
 constexpr int kDkQ = 32;        // query rows per streamed tile in kernel 2
 
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
 template <int D, bool CAUSAL>
-__global__ void __launch_bounds__(512, 2) fa2_bwd_dq_kernel(BwdArgs p)
+__global__ void __launch_bounds__(256, 1) fa2_bwd_dq_kernel(BwdArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWB = D * 2;
     constexpr int TILEB = kDqKV * ROWB;
+    constexpr int BUFB = 2 * TILEB;           // K tile | V tile
     constexpr int CPR = D / 8;
-    constexpr int CPT = kDqKV * CPR / 512;
+    constexpr int RPI = 64 / CPR;
+    constexpr int NP = kDqKV / RPI;           // DMA pieces per tensor per tile
     constexpr int KS = D / 16;
     constexpr int DT = D / 32;
+    // AGPR map
+    constexpr int A_DQ = 0;                   // dQ^T tile (qb, dt): a[A_DQ + (qb*DT + dt)*16 ..+15]
+    constexpr int A_QF = 128;                 // Q fragment (qb, s): a[A_QF + (qb*KS + s)*4 ..+3]
+    constexpr int A_GF = 192;                 // dO fragment (qb, s)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -101,142 +119,182 @@ __global__ void __launch_bounds__(512, 2) fa2_bwd_dq_kernel(BwdArgs p)
     const char* Vh = (const char*)p.V + slab;
     const char* Gh = (const char*)p.dO + slab;
 
-    const int q0 = rb * kBwdRows + wave * 32;
-    const int qrow = q0 + qi;
-    const int qld = qrow < N ? qrow : N - 1;
+    const int q0 = rb * kBwdRows + wave * 64;
 
     int ntiles = (N + kDqKV - 1) / kDqKV;
     if (CAUSAL) ntiles = min(ntiles, min(rb * kBwdRows + kBwdRows - 1, N - 1) / kDqKV + 1);
+    const int tend = (ntiles + 1) & ~1;       // whole pairs; a padding tile is fully masked
 
-    bf16x8 qf[KS], gf[KS];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        qf[s] = *reinterpret_cast<const bf16x8*>(Qh + (size_t)qld * ROWB + 16 * (2 * s + h));
-        gf[s] = *reinterpret_cast<const bf16x8*>(Gh + (size_t)qld * ROWB + 16 * (2 * s + h));
-    }
-    const float Lq = p.L[(size_t)head * N + qld] * kLog2e;
-    const float Dq = p.D[(size_t)head * N + qld];
+    // ---- resident operands -> AGPRs; per-row constants
+    int qrow[2];
+    float Lq[2], Dq[2];
+    static_for<2>([&](auto QB) {
+        constexpr int qb = decltype(QB)::value;
+        qrow[qb] = q0 + 32 * qb + qi;
+        const int qld = qrow[qb] < N ? qrow[qb] : N - 1;
+        static_for<KS>([&](auto S) {
+            constexpr int sidx = decltype(S)::value;
+            acc_write_frag<A_QF + (qb * KS + sidx) * 4>(
+                *reinterpret_cast<const bf16x8*>(Qh + (size_t)qld * ROWB + 16 * (2 * sidx + h)));
+            acc_write_frag<A_GF + (qb * KS + sidx) * 4>(
+                *reinterpret_cast<const bf16x8*>(Gh + (size_t)qld * ROWB + 16 * (2 * sidx + h)));
+        });
+        static_for<16 * DT>([&](auto R) { acc_write<A_DQ + qb * DT * 16 + decltype(R)::value>(0.0f); });
+        Lq[qb] = p.L[(size_t)head * N + qld] * kLog2e;
+        Dq[qb] = p.D[(size_t)head * N + qld];
+    });
     const float c2 = p.scale * kLog2e;
 
-    f32x16 dqacc[DT];
+    // ---- LDS-DMA staging (as in fa2_fwd: one per-lane voffset, wave-uniform soffset, range-checked)
+    const int drow = lane / CPR;
+    const int dslot = lane % CPR;
+    const int prow = wave * RPI + drow;
+    const int doff = drow * ROWB + 16 * ((lds_off<D>(prow, dslot) - ROWB * prow) >> 4);
+    const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, N * ROWB, 0x00020000);
+    const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, N * ROWB, 0x00020000);
+    auto stage = [&](int t, int buf) {
+        char* b = smem + buf * BUFB;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dqacc[dt][r] = 0.0f;
-
-    u32x4 kreg[CPT], vreg[CPT];
-    auto stage_load = [&](int t) {
-#pragma unroll
-        for (int i = 0; i < CPT; ++i) {
-            const int c = tid + 512 * i;
-            const int row = c / CPR, ch = c % CPR;
-            int krow = t * kDqKV + row;
-            krow = krow < N ? krow : N - 1;
-            kreg[i] = *reinterpret_cast<const u32x4*>(Kh + (size_t)krow * ROWB + 16 * ch);
-            vreg[i] = *reinterpret_cast<const u32x4*>(Vh + (size_t)krow * ROWB + 16 * ch);
+        for (int j = wave; j < 2 * NP; j += kDqWaves) {
+            const int which = j / NP, piece = j % NP;
+            const int soff = (t * kDqKV + piece * RPI) * ROWB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(which ? v_rsrc : k_rsrc, (lptr_t)(b + which * TILEB + piece * 1024),
+                                                     16, doff, soff, 0, 0);
         }
     };
-    auto stage_write = [&](int buf) {
-        char* kb = smem + buf * 2 * TILEB;
-#pragma unroll
-        for (int i = 0; i < CPT; ++i) {
-            const int c = tid + 512 * i;
-            const int row = c / CPR, ch = c % CPR;
-            const int o = lds_off<D>(row, ch);
-            *reinterpret_cast<u32x4*>(kb + o) = kreg[i];
-            *reinterpret_cast<u32x4*>(kb + TILEB + o) = vreg[i];
-        }
-    };
-
-    if (ntiles > 0) {
-        stage_load(0);
-        stage_write(0);
-    }
+    if (tend > 0) stage(0, 0);
     __syncthreads();
 
+    // ---- loop-invariant per-lane LDS offsets
     const int trq = (lane & 15) >> 2;
     const int trp = lane & 3;
     const int trcb = (lane >> 4) & 1;
+    int roff[KS], toff[DT][2];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) roff[s] = lds_off<D>(qi, 2 * s + h);            // +32 rows: kb = 1
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)      // +16 rows: sp = 1, +32 rows: kb = 1
+            toff[dt][jj] = lds_off<D>(8 * jj + 4 * h + trq, 4 * dt + 2 * trcb + (trp >> 1)) + 8 * (trp & 1);
+    const uint32_t lbase = (uint32_t)(uintptr_t)smem;
 
-    for (int t = 0; t < ntiles; ++t) {
-        const char* Kt = smem + (t & 1) * 2 * TILEB;
+    auto tile = [&](auto BUF, int t) {
+        constexpr int buf = decltype(BUF)::value;
+        constexpr int KB = buf * BUFB;
+        const char* Kt = smem + KB;
         const char* Vt = Kt + TILEB;
-        const bool more = t + 1 < ntiles;
-        if (more) stage_load(t + 1);
-
+        if (t + 1 < tend) stage(t + 1, buf ^ 1);
         const int key0 = t * kDqKV;
-        bool active = true;
-        if (CAUSAL) active = key0 <= q0 + 31;
 
-        if (active) {
-            const bool tail = key0 + kDqKV > N;
-            bool diag = false;
-            if (CAUSAL) diag = key0 + kDqKV - 1 > q0;
-
-            bf16x8 dsf[2][2];
+        // ---- S^T[key][q] and dP^T[key][q] of the 64 keys for both row blocks
+        f32x16 sacc[2][2], dpacc[2][2];      // [qb][kb]
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                f32x16 sacc, dpacc;
+        for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { sacc[r] = 0.0f; dpacc[r] = 0.0f; }
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    const int o = lds_off<D>(32 * kb + qi, 2 * s + h);
-                    sacc = mfma32(lds_read_frag(Kt, o), qf[s], sacc);     // S^T[key][q]
-                    dpacc = mfma32(lds_read_frag(Vt, o), gf[s], dpacc);   // dP^T[key][q]
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float pr = __builtin_amdgcn_exp2f(sacc[r] * c2 - Lq);
-                    if (tail || diag) {
-                        const int key = key0 + 32 * kb + acc_row(r, h);
-                        bool dead = key >= N;
-                        if (CAUSAL) dead = dead || key > qrow;
-                        if (dead) pr = 0.0f;
-                    }
-                    sacc[r] = pr * (dpacc[r] - Dq);                        // dS^T[key][q]
-                }
-                dsf[kb][0] = pack_acc(sacc, 0);
-                dsf[kb][1] = pack_acc(sacc, 1);
+                for (int r = 0; r < 16; ++r) { sacc[qb][kb][r] = 0.0f; dpacc[qb][kb][r] = 0.0f; }
+        bf16x8 ka = lds_read_frag(Kt, roff[0]), va = lds_read_frag(Vt, roff[0]);
+        static_for<2 * KS>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            constexpr int kb = i / KS, sidx = i % KS;
+            bf16x8 kn = ka, vn = va;
+            if constexpr (i + 1 < 2 * KS) {
+                constexpr int o = ((i + 1) / KS) * 32 * ROWB;
+                kn = lds_read_frag(Kt, roff[(i + 1) % KS] + o);
+                vn = lds_read_frag(Vt, roff[(i + 1) % KS] + o);
             }
-
-            // dQ^T[dcol][q] += K^T[dcol][key] dS^T[key][q]
+            mfma_bagpr<A_QF + (0 * KS + sidx) * 4>(sacc[0][kb], ka);
+            mfma_bagpr<A_QF + (1 * KS + sidx) * 4>(sacc[1][kb], ka);
+            mfma_bagpr<A_GF + (0 * KS + sidx) * 4>(dpacc[0][kb], va);
+            mfma_bagpr<A_GF + (1 * KS + sidx) * 4>(dpacc[1][kb], va);
+            ka = kn; va = vn;
+        });
+        // first K^T fragment goes out before the arithmetic
+        bf16x4 ta0 = lds_read_tr_asm<KB>(lbase + toff[0][0]), ta1 = lds_read_tr_asm<KB>(lbase + toff[0][1]);
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) { mfma_vgpr_settle(sacc[qb][kb]); mfma_vgpr_settle(dpacc[qb][kb]); }
+
+        // ---- P = exp2(c S - L), dS = P (dP - D); masks fold into P
+        const bool tail = key0 + kDqKV > N;
+        bool diag = false;
+        if (CAUSAL) diag = key0 + kDqKV - 1 > q0;
+        bf16x8 dsf[2][2][2];                   // [qb][kb][sp]
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    sacc[qb][kb][r] = __builtin_amdgcn_exp2f(sacc[qb][kb][r] * c2 - Lq[qb]);
+        if (tail || diag) {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                    for (int sp = 0; sp < 2; ++sp) {
-                        bf16x4 part[2];
-#pragma unroll
-                        for (int jj = 0; jj < 2; ++jj) {
-                            const int row = 32 * kb + 16 * sp + 8 * jj + 4 * h + trq;
-                            const int ch = 4 * dt + 2 * trcb + (trp >> 1);
-                            part[jj] = lds_read_tr(Kt, lds_off<D>(row, ch) + 8 * (trp & 1));
-                        }
-                        bf16x8 kf;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { kf[e] = part[0][e]; kf[4 + e] = part[1][e]; }
-                        dqacc[dt] = mfma32(kf, dsf[kb][sp], dqacc[dt]);
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = key0 + 32 * kb + acc_row(r, h);
+                        bool dead = key >= N;
+                        if (CAUSAL) dead = dead || key > qrow[qb];
+                        if (dead) sacc[qb][kb][r] = 0.0f;
                     }
         }
-
-        if (more) stage_write((t + 1) & 1);
-        __syncthreads();
-    }
-
-    if (qrow < N) {
-        char* dQq = (char*)p.dQ + slab + (size_t)qrow * ROWB;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+        for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                bf16x4 o;
+            for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (__bf16)(dqacc[dt][4 * g + e] * p.scale);
-                *reinterpret_cast<bf16x4*>(dQq + 2 * (32 * dt + 8 * g + 4 * h)) = o;
+                for (int r = 0; r < 16; ++r) dpacc[qb][kb][r] = sacc[qb][kb][r] * (dpacc[qb][kb][r] - Dq[qb]);
+                dsf[qb][kb][0] = pack_acc(dpacc[qb][kb], 0);
+                dsf[qb][kb][1] = pack_acc(dpacc[qb][kb], 1);
             }
+
+        // ---- dQ^T[dcol][q] += K^T[dcol][key] dS^T[key][q] : group g = (dt, kb, sp)
+        static_for<4 * DT>([&](auto G) {
+            constexpr int g = decltype(G)::value;
+            constexpr int dt = g >> 2, kb = (g >> 1) & 1, sp = g & 1;
+            bf16x4 tn0 = ta0, tn1 = ta1;
+            if constexpr (g + 1 < 4 * DT) {
+                constexpr int dtn = (g + 1) >> 2;
+                constexpr int o = KB + (((g + 1) >> 1) & 1) * 32 * ROWB + ((g + 1) & 1) * 16 * ROWB;
+                tn0 = lds_read_tr_asm<o>(lbase + toff[dtn][0]);
+                tn1 = lds_read_tr_asm<o>(lbase + toff[dtn][1]);
+                lds_tr_wait2<2>(ta0, ta1);
+            } else {
+                lds_tr_wait2<0>(ta0, ta1);
+            }
+            bf16x8 kT;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { kT[e] = ta0[e]; kT[4 + e] = ta1[e]; }
+            acc_mfma<A_DQ + (0 * DT + dt) * 16>(kT, dsf[0][kb][sp]);
+            acc_mfma<A_DQ + (1 * DT + dt) * 16>(kT, dsf[1][kb][sp]);
+            ta0 = tn0; ta1 = tn1;
+        });
+        __syncthreads();     // drains this wave's DMA (vmcnt) and hands the buffers over
+    };
+
+    for (int t = 0; t < tend; t += 2) {
+        tile(std::integral_constant<int, 0>{}, t);
+        tile(std::integral_constant<int, 1>{}, t + 1);
     }
+
+    mfma_acc_settle();
+    static_for<2>([&](auto QB) {
+        constexpr int qb = decltype(QB)::value;
+        static_for<4 * DT>([&](auto G) {
+            constexpr int dt = decltype(G)::value / 4, g = decltype(G)::value % 4;
+            constexpr int R = A_DQ + (qb * DT + dt) * 16 + 4 * g;
+            bf16x4 o;
+            o[0] = (__bf16)(acc_read<R>() * p.scale); o[1] = (__bf16)(acc_read<R + 1>() * p.scale);
+            o[2] = (__bf16)(acc_read<R + 2>() * p.scale); o[3] = (__bf16)(acc_read<R + 3>() * p.scale);
+            if (qrow[qb] < N)
+                *reinterpret_cast<bf16x4*>((char*)p.dQ + slab + (size_t)qrow[qb] * ROWB + 2 * (32 * dt + 8 * g + 4 * h)) = o;
+        });
+    });
 }
 
 // --------------------------------------------------------------------------- kernel 2: dK, dV
@@ -256,9 +314,6 @@ __global__ void __launch_bounds__(512, 2) fa2_bwd_dq_kernel(BwdArgs p)
 //     an immediate.
 constexpr int kDkWaves = 4;
 constexpr int kDkKeys = 64 * kDkWaves;      // keys per workgroup
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int D, bool CAUSAL>
 __global__ void __launch_bounds__(256, 1) fa2_bwd_dkdv_kernel(BwdArgs p)
@@ -548,7 +603,7 @@ static hipError_t launch_bwd_one(const BwdArgs& a, hipStream_t stream)
     e = ensure_dynamic_lds(fa2_bwd_dkdv_kernel<D, CAUSAL>, lds_dk, set_dk);
     if (e != hipSuccess) return e;
     if (a.phases & 2) {
-        hipLaunchKernelGGL((fa2_bwd_dq_kernel<D, CAUSAL>), dim3((unsigned)(nb * a.BH)), dim3(512), lds_dq, stream, a);
+        hipLaunchKernelGGL((fa2_bwd_dq_kernel<D, CAUSAL>), dim3((unsigned)(nb * a.BH)), dim3(256), lds_dq, stream, a);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }

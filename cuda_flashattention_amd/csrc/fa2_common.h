@@ -12,6 +12,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+#include <utility>
+
 namespace fa2 {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -108,6 +111,114 @@ __device__ __forceinline__ void mfma_acc_settle()
 {
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 }
+
+// ---------------------------------------------------------------------------------------
+// Accumulator tiles owned by the kernel, not by hipcc: literal AGPR ranges a[LO : LO+15] that only
+// these helpers touch (the clobber list reserves the whole accumulator file a0..a255 for them, so
+// hipcc allocates nothing there).  Taking a long-lived MFMA accumulator out of C++ dataflow this way means no phi, no
+// copy and no spill can ever involve it -- in particular a conditional rescale of the tile costs
+// nothing when not taken.  The asm is opaque to hipcc's hazard recogniser: acc_mfma carries
+// `s_nop 1` for a VALU-written operand, and any non-MFMA access to a tile an MFMA may still be
+// writing must be preceded by mfma_acc_settle().
+// ---------------------------------------------------------------------------------------
+#define FA2_ACC_CLOBBERS \
+    "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", \
+    "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", \
+    "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", \
+    "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", \
+    "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", \
+    "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", \
+    "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", \
+    "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", \
+    "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", \
+    "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", \
+    "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", \
+    "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", \
+    "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", \
+    "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", \
+    "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", \
+    "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
+
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+// f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N-1>{})
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+template <int LO>
+__device__ __forceinline__ void acc_mfma(bf16x8 a, bf16x8 b)
+{
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]"
+                 : : "v"(a), "v"(b), "i"(LO), "i"(LO + 15) : FA2_ACC_CLOBBERS);
+}
+// Product whose B operand is a fragment resident in literal AGPRs a[BLO : BLO+3] (an operand that
+// never changes during the kernel, e.g. the Q fragments of a query block) and whose accumulator is
+// an ordinary VGPR tile the VALU reads afterwards: c += a * a[BLO:BLO+3].  Whoever reads c with
+// non-MFMA code must first execute mfma_vgpr_settle(c).
+template <int BLO>
+__device__ __forceinline__ void mfma_bagpr(f32x16& c, bf16x8 a)
+{
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0"
+                 : "+v"(c) : "v"(a), "i"(BLO), "i"(BLO + 3) : FA2_ACC_CLOBBERS);
+}
+__device__ __forceinline__ void mfma_vgpr_settle(f32x16& c)
+{
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(c));
+}
+// Parks a bf16x8 fragment in a[LO : LO+3].
+template <int LO>
+__device__ __forceinline__ void acc_write_frag(bf16x8 f)
+{
+    const u32x4 w = __builtin_bit_cast(u32x4, f);
+    asm volatile("v_accvgpr_write_b32 a[%c4], %0\n\tv_accvgpr_write_b32 a[%c5], %1\n\t"
+                 "v_accvgpr_write_b32 a[%c6], %2\n\tv_accvgpr_write_b32 a[%c7], %3"
+                 : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "i"(LO), "i"(LO + 1), "i"(LO + 2), "i"(LO + 3)
+                 : FA2_ACC_CLOBBERS);
+}
+
+template <int R>
+__device__ __forceinline__ float acc_read()
+{
+    float x;
+    asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(x) : "i"(R));
+    return x;
+}
+template <int R>
+__device__ __forceinline__ void acc_write(float x)
+{
+    asm volatile("v_accvgpr_write_b32 a[%c1], %0" : : "v"(x), "i"(R) : FA2_ACC_CLOBBERS);
+}
+// a[R .. R+3] *= alpha
+template <int R>
+__device__ __forceinline__ void acc_scale4(float alpha)
+{
+    float t0, t1, t2, t3;
+    asm volatile("v_accvgpr_read_b32 %0, a[%c5]\n\tv_accvgpr_read_b32 %1, a[%c6]\n\t"
+                 "v_accvgpr_read_b32 %2, a[%c7]\n\tv_accvgpr_read_b32 %3, a[%c8]\n\t"
+                 "v_mul_f32 %0, %0, %4\n\tv_mul_f32 %1, %1, %4\n\tv_mul_f32 %2, %2, %4\n\tv_mul_f32 %3, %3, %4\n\t"
+                 "v_accvgpr_write_b32 a[%c5], %0\n\tv_accvgpr_write_b32 a[%c6], %1\n\t"
+                 "v_accvgpr_write_b32 a[%c7], %2\n\tv_accvgpr_write_b32 a[%c8], %3"
+                 : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+                 : "v"(alpha), "i"(R), "i"(R + 1), "i"(R + 2), "i"(R + 3) : FA2_ACC_CLOBBERS);
+}
+
+// Makes a value opaque at this point of the program: hipcc cannot schedule its producers below
+// or its consumers above this statement, and -- being volatile -- the statement keeps its place
+// among the other asm statements (MFMAs, transposed reads, waits).  Used to pin VALU work between
+// the asm-issued MFMA groups it is meant to run beside.
+__device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
+
+// Keeps an MFMA operand's registers allocated up to this point.  hipcc sees an asm-issued MFMA as
+// an instruction that has read its operands once issued, and may hand a dead operand register to
+// the very next VALU instruction as a temporary -- while the matrix pipe is still reading it
+// (observed: wrong products at D = 64).  Place after the VALU work that follows the MFMA.
+__device__ __forceinline__ void keep_alive(const bf16x8& x) { asm volatile("" : : "v"(x)); }
 
 // Value held by the same lane index in the OTHER 32-lane half of the wave.
 __device__ __forceinline__ float other_half(float x)
