@@ -179,22 +179,44 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dq_kernel(BwdArgs p)
             toff[dt][jj] = lds_off<D>(8 * jj + 4 * h + trq, 4 * dt + 2 * trcb + (trp >> 1)) + 8 * (trp & 1);
     const uint32_t lbase = (uint32_t)(uintptr_t)smem;
 
-    auto tile = [&](auto BUF, int t) {
+    // MASKED selects the variant that applies the key-tail / causal masks (a few tiles per
+    // workgroup); the common variant carries no mask arithmetic at all.
+    auto tile_body = [&](auto BUF, auto MASKED_, int t) {
         constexpr int buf = decltype(BUF)::value;
+        constexpr bool MASKED = decltype(MASKED_)::value;
         constexpr int KB = buf * BUFB;
         const char* Kt = smem + KB;
         const char* Vt = Kt + TILEB;
         if (t + 1 < tend) stage(t + 1, buf ^ 1);
         const int key0 = t * kDqKV;
 
-        // ---- S^T[key][q] and dP^T[key][q] of the 64 keys for both row blocks
-        f32x16 sacc[2][2], dpacc[2][2];      // [qb][kb]
+        f32x16 sacc[2][2], dpacc[2][2];      // [qb][kb]: S^T[key][q], dP^T[key][q]
+
+        // dS of registers [r0, r0 + n) of key block kb, both row blocks, in place in dpacc:
+        // P = exp2(c S - L), dS = P (dP - D).  pin() keeps the chunk behind the asm MFMAs issued
+        // before it in program order (the S/dP products of block kb are at least four MFMA issues
+        // old by then, i.e. retired), the sched_barrier after each call keeps it in front of the next.
+        auto ds_chunk = [&](int kb, int r0, int n) {
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
+            for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { sacc[qb][kb][r] = 0.0f; dpacc[qb][kb][r] = 0.0f; }
+                for (int r = r0; r < r0 + n; ++r) {
+                    float sv = sacc[qb][kb][r];
+                    pin(sv);
+                    float pr = __builtin_amdgcn_exp2f(sv * c2 - Lq[qb]);
+                    if constexpr (MASKED) {
+                        const int key = key0 + 32 * kb + acc_row(r, h);
+                        bool dead = key >= N;
+                        if (CAUSAL) dead = dead || key > qrow[qb];
+                        if (dead) pr = 0.0f;
+                    }
+                    dpacc[qb][kb][r] = pr * (dpacc[qb][kb][r] - Dq[qb]);
+                }
+        };
+
+        // ---- stage 1: S^T and dP^T, key block 0 then 1; the dS arithmetic of block 0 runs between
+        // the MFMA groups of block 1
+        constexpr int RP1 = 16 / KS;          // registers per row block handled beside one k-step
         bf16x8 ka = lds_read_frag(Kt, roff[0]), va = lds_read_frag(Vt, roff[0]);
         static_for<2 * KS>([&](auto I) {
             constexpr int i = decltype(I)::value;
@@ -205,62 +227,45 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dq_kernel(BwdArgs p)
                 kn = lds_read_frag(Kt, roff[(i + 1) % KS] + o);
                 vn = lds_read_frag(Vt, roff[(i + 1) % KS] + o);
             }
-            mfma_bagpr<A_QF + (0 * KS + sidx) * 4>(sacc[0][kb], ka);
-            mfma_bagpr<A_QF + (1 * KS + sidx) * 4>(sacc[1][kb], ka);
-            mfma_bagpr<A_GF + (0 * KS + sidx) * 4>(dpacc[0][kb], va);
-            mfma_bagpr<A_GF + (1 * KS + sidx) * 4>(dpacc[1][kb], va);
+            if constexpr (sidx == 0) {
+                mfma_bagpr_init<A_QF + (0 * KS + sidx) * 4>(sacc[0][kb], ka);
+                mfma_bagpr_init<A_QF + (1 * KS + sidx) * 4>(sacc[1][kb], ka);
+                mfma_bagpr_init<A_GF + (0 * KS + sidx) * 4>(dpacc[0][kb], va);
+                mfma_bagpr_init<A_GF + (1 * KS + sidx) * 4>(dpacc[1][kb], va);
+            } else {
+                mfma_bagpr<A_QF + (0 * KS + sidx) * 4>(sacc[0][kb], ka);
+                mfma_bagpr<A_QF + (1 * KS + sidx) * 4>(sacc[1][kb], ka);
+                mfma_bagpr<A_GF + (0 * KS + sidx) * 4>(dpacc[0][kb], va);
+                mfma_bagpr<A_GF + (1 * KS + sidx) * 4>(dpacc[1][kb], va);
+            }
+            if constexpr (kb == 1) {
+                ds_chunk(0, sidx * RP1, RP1);
+                keep_alive(ka); keep_alive(va);
+            }
             ka = kn; va = vn;
+            __builtin_amdgcn_sched_barrier(0);
         });
-        // first K^T fragment goes out before the arithmetic
-        bf16x4 ta0 = lds_read_tr_asm<KB>(lbase + toff[0][0]), ta1 = lds_read_tr_asm<KB>(lbase + toff[0][1]);
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) { mfma_vgpr_settle(sacc[qb][kb]); mfma_vgpr_settle(dpacc[qb][kb]); }
-
-        // ---- P = exp2(c S - L), dS = P (dP - D); masks fold into P
-        const bool tail = key0 + kDqKV > N;
-        bool diag = false;
-        if (CAUSAL) diag = key0 + kDqKV - 1 > q0;
         bf16x8 dsf[2][2][2];                   // [qb][kb][sp]
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    sacc[qb][kb][r] = __builtin_amdgcn_exp2f(sacc[qb][kb][r] * c2 - Lq[qb]);
-        if (tail || diag) {
-#pragma unroll
-            for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = key0 + 32 * kb + acc_row(r, h);
-                        bool dead = key >= N;
-                        if (CAUSAL) dead = dead || key > qrow[qb];
-                        if (dead) sacc[qb][kb][r] = 0.0f;
-                    }
+        for (int qb = 0; qb < 2; ++qb) {
+            dsf[qb][0][0] = pack_acc(dpacc[qb][0], 0);
+            dsf[qb][0][1] = pack_acc(dpacc[qb][0], 1);
         }
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dpacc[qb][kb][r] = sacc[qb][kb][r] * (dpacc[qb][kb][r] - Dq[qb]);
-                dsf[qb][kb][0] = pack_acc(dpacc[qb][kb], 0);
-                dsf[qb][kb][1] = pack_acc(dpacc[qb][kb], 1);
-            }
+        // first K^T fragment goes out, then the block-1 products get time to retire
+        bf16x4 ta0 = lds_read_tr_asm<KB>(lbase + toff[0][0]), ta1 = lds_read_tr_asm<KB>(lbase + toff[0][1]);
+        mfma_vgpr_settle(sacc[1][1]);
+        __builtin_amdgcn_sched_barrier(0);
 
-        // ---- dQ^T[dcol][q] += K^T[dcol][key] dS^T[key][q] : group g = (dt, kb, sp)
+        // ---- stage 2: dQ^T[dcol][q] += K^T[dcol][key] dS^T[key][q], group g = (kb, dt, sp); the dS
+        // arithmetic of block 1 runs between the groups of block 0
+        constexpr int RP2 = 16 / (2 * DT);
         static_for<4 * DT>([&](auto G) {
             constexpr int g = decltype(G)::value;
-            constexpr int dt = g >> 2, kb = (g >> 1) & 1, sp = g & 1;
+            constexpr int kb = g / (2 * DT), dt = (g % (2 * DT)) >> 1, sp = g & 1;
             bf16x4 tn0 = ta0, tn1 = ta1;
             if constexpr (g + 1 < 4 * DT) {
-                constexpr int dtn = (g + 1) >> 2;
-                constexpr int o = KB + (((g + 1) >> 1) & 1) * 32 * ROWB + ((g + 1) & 1) * 16 * ROWB;
+                constexpr int kbn = (g + 1) / (2 * DT), dtn = ((g + 1) % (2 * DT)) >> 1, spn = (g + 1) & 1;
+                constexpr int o = KB + kbn * 32 * ROWB + spn * 16 * ROWB;
                 tn0 = lds_read_tr_asm<o>(lbase + toff[dtn][0]);
                 tn1 = lds_read_tr_asm<o>(lbase + toff[dtn][1]);
                 lds_tr_wait2<2>(ta0, ta1);
@@ -273,10 +278,29 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dq_kernel(BwdArgs p)
             acc_mfma<A_DQ + (0 * DT + dt) * 16>(kT, dsf[0][kb][sp]);
             acc_mfma<A_DQ + (1 * DT + dt) * 16>(kT, dsf[1][kb][sp]);
             ta0 = tn0; ta1 = tn1;
+            if constexpr (kb == 0) {
+                ds_chunk(1, (g % (2 * DT)) * RP2, RP2);
+                keep_alive(kT);
+                if constexpr (g == 2 * DT - 1) {
+#pragma unroll
+                    for (int qb = 0; qb < 2; ++qb) {
+                        dsf[qb][1][0] = pack_acc(dpacc[qb][1], 0);
+                        dsf[qb][1][1] = pack_acc(dpacc[qb][1], 1);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         });
         __syncthreads();     // drains this wave's DMA (vmcnt) and hands the buffers over
     };
 
+    auto tile = [&](auto BUF, int t) {
+        const int key0 = t * kDqKV;
+        bool masked = key0 + kDqKV > N;
+        if (CAUSAL) masked = masked || key0 + kDqKV - 1 > q0;
+        if (masked) tile_body(BUF, std::true_type{}, t);
+        else tile_body(BUF, std::false_type{}, t);
+    };
     for (int t = 0; t < tend; t += 2) {
         tile(std::integral_constant<int, 0>{}, t);
         tile(std::integral_constant<int, 1>{}, t + 1);
