@@ -344,11 +344,13 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dkdv_kernel(BwdArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWB = D * 2;
-    constexpr int TILEB = kDkQ * ROWB;          // Q (or dO) tile: 32 rows
-    constexpr int BUFB = 2 * TILEB + 256;       // Q tile, dO tile, 32 x (-L/scale), 32 x (-D)
+    constexpr int TROWS = 2 * kDkQ;             // rows per DMA tile: two 32-row sub-tiles, one barrier
+    constexpr int TILEB = TROWS * ROWB;         // Q (or dO) tile
+    constexpr int HALFB = kDkQ * ROWB;          // one sub-tile
+    constexpr int BUFB = 2 * TILEB + 512;       // Q tile, dO tile, 64 x (-L/scale), 64 x (-D)
     constexpr int CPR = D / 8;                  // 16-byte chunks per row
     constexpr int RPI = 64 / CPR;               // rows one DMA wave-instruction covers (1 KiB)
-    constexpr int NINS = kDkQ / RPI;            // DMA instructions per tensor per tile: 8 or 4
+    constexpr int NINS = TROWS / RPI;           // DMA instructions per tensor per tile: 16 or 8
     constexpr int KS = D / 16;
     constexpr int DT = D / 32;
 
@@ -402,9 +404,9 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dkdv_kernel(BwdArgs p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { dkacc[kb][dt][r] = 0.0f; dvacc[kb][dt][r] = 0.0f; }
 
-    const int ntiles = (N + kDkQ - 1) / kDkQ;
+    const int ntiles = (N + TROWS - 1) / TROWS;
     int t0 = 0;
-    if (CAUSAL) t0 = (cb * kDkKeys) / kDkQ;         // earlier query rows see none of these keys
+    if (CAUSAL) t0 = (cb * kDkKeys) / TROWS;        // earlier query rows see none of these keys
     // Always whole pairs of tiles (the loop is unrolled by two and must not branch around the
     // second tile: a branch there makes hipcc shuttle the AGPR-pinned accumulators through
     // copies).  An odd count is padded with one tile past the sequence end: all rows masked.
@@ -428,18 +430,18 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dkdv_kernel(BwdArgs p)
     const auto q_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Qh, 0, N * ROWB, 0x00020000);
     const auto g_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Gh, 0, N * ROWB, 0x00020000);
     const auto rc_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.RC, 0, (int)(2 * rc_plane * 4), 0x00020000);
-    const int rcoff = (int)(((lane < 32 ? 0 : rc_plane) + (size_t)head * N + (lane & 31)) * 4);
+    const int rcoff = (int)(((wave == 0 ? 0 : rc_plane) + (size_t)head * N + lane) * 4);
     auto stage = [&](int t, int buf) {
         char* b = bufs + buf * BUFB;
 #pragma unroll
         for (int j = wave; j < 2 * NINS; j += kDkWaves) {
             const int which = j / NINS, piece = j % NINS;
-            const int soff = (t * kDkQ + piece * RPI) * ROWB;             // wave-uniform
+            const int soff = (t * TROWS + piece * RPI) * ROWB;            // wave-uniform
             __builtin_amdgcn_raw_ptr_buffer_load_lds(which ? g_rsrc : q_rsrc, (lptr_t)(b + which * TILEB + piece * 1024),
                                                      16, doff, soff, 0, 0);
         }
-        if (wave == 0)                               // 64 row constants: lanes 0-31 -L/scale, 32-63 -D
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rc_rsrc, (lptr_t)(b + 2 * TILEB), 4, rcoff, t * kDkQ * 4, 0, 0);
+        if (wave < 2)                                // row constants: wave 0 the 64 x -L/scale, wave 1 the 64 x -D
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rc_rsrc, (lptr_t)(b + 2 * TILEB + wave * 256), 4, rcoff, t * TROWS * 4, 0, 0);
     };
 
     if (t0 < tend) stage(t0, 0);                     // tile t lives in buffer (t - t0) & 1
@@ -461,64 +463,70 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dkdv_kernel(BwdArgs p)
         for (int jj = 0; jj < 2; ++jj)
             toff[dt][jj] = lds_off<D>(8 * jj + 4 * h + trq, 4 * dt + 2 * trcb + (trp >> 1)) + 8 * (trp & 1);   // +16 rows: sp = 1
 
-    auto tile = [&](auto BUF, int t) {
+    // One 32-row sub-tile SH of the 64-row tile t living in buffer BUF.
+    auto sub = [&](auto BUF, auto SH, int t) {
         constexpr int buf = decltype(BUF)::value;
-        const char* Qt = smem + buf * BUFB;
+        constexpr int sh = decltype(SH)::value;
+        const char* Qt = smem + buf * BUFB + sh * HALFB;
         const char* Gt = Qt + TILEB;
-        const float* rcs = reinterpret_cast<const float*>(Qt + 2 * TILEB);
-        if (t + 1 < tend) stage(t + 1, buf ^ 1);
+        const float* rcs = reinterpret_cast<const float*>(smem + buf * BUFB + 2 * TILEB) + 32 * sh;
 
-        const int qb0 = t * kDkQ;
+        const int qb0 = t * TROWS + 32 * sh;
         // accumulators start from the row constants: S' = Q K^T - L/scale, dP' = dO V^T - D
         f32x16 sacc[2], dpacc[2];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x4 a = *reinterpret_cast<const f32x4*>(rcs + 8 * g + 4 * h);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(rcs + 32 + 8 * g + 4 * h);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(rcs + 64 + 8 * g + 4 * h);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 sacc[0][4 * g + e] = a[e]; sacc[1][4 * g + e] = a[e];
                 dpacc[0][4 * g + e] = b[e]; dpacc[1][4 * g + e] = b[e];
             }
         }
-        // S' and dP', fragments read one k-step ahead
-        bf16x8 qa = lds_read_frag(Qt, roff[0]), ga = lds_read_frag(Gt, roff[0]);
-        bf16x8 v0 = lds_read_frag(Vw, roff[0]), v1 = lds_read_frag(Vw, roff[0] + 32 * ROWB);
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            bf16x8 qn = qa, gn = ga, v0n = v0, v1n = v1;
-            if (s + 1 < KS) {
-                qn = lds_read_frag(Qt, roff[s + 1]);
-                gn = lds_read_frag(Gt, roff[s + 1]);
-                v0n = lds_read_frag(Vw, roff[s + 1]);
-                v1n = lds_read_frag(Vw, roff[s + 1] + 32 * ROWB);
-            }
-            sacc[0] = mfma32(qa, kf[0][s], sacc[0]);                 // S'[q][key]
-            sacc[1] = mfma32(qa, kf[1][s], sacc[1]);
-            dpacc[0] = mfma32(ga, v0, dpacc[0]);                     // dP'[q][key]
-            dpacc[1] = mfma32(ga, v1, dpacc[1]);
-            qa = qn; ga = gn; v0 = v0n; v1 = v1n;
-        }
+        // ---- stage A: S'[q][key] for both key blocks, Q row fragments read one k-step ahead
+        bf16x8 qa = lds_read_frag(Qt, roff[0]);
+        static_for<KS>([&](auto S) {
+            constexpr int sidx = decltype(S)::value;
+            bf16x8 qn = qa;
+            if constexpr (sidx + 1 < KS) qn = lds_read_frag(Qt, roff[sidx + 1]);
+            mfma_vv(sacc[0], qa, kf[0][sidx]);
+            mfma_vv(sacc[1], qa, kf[1][sidx]);
+            qa = qn;
+        });
+        __builtin_amdgcn_sched_barrier(0);
 
-        // first transposed fragments go out before the softmax arithmetic (asm form: see
-        // lds_read_tr_asm -- the builtin would wait for the DMA issued at the top of the tile)
-        constexpr int QB = buf * BUFB, GB = buf * BUFB + TILEB, SPB = 16 * ROWB;
-        const uint32_t lbase = (uint32_t)(uintptr_t)smem;
-        bf16x4 gp0 = lds_read_tr_asm<GB>(lbase + toff[0][0]), gp1 = lds_read_tr_asm<GB>(lbase + toff[0][1]);
-        bf16x4 qp0 = lds_read_tr_asm<QB>(lbase + toff[0][0]), qp1 = lds_read_tr_asm<QB>(lbase + toff[0][1]);
-
-        // masks as two per-lane bounds on the accumulator's row constant (r&3) + 8(r>>2): a query
-        // row is dead when it lies past the sequence end or (causal) above the key.
+        // ---- stage B: dP'[q][key] (dO rows x the V image) beside P = exp2(c S') of the finished S'
         const bool tail = qb0 + kDkQ > N;
         bool diag = false;
         if (CAUSAL) diag = qb0 < kw0 + 63;
-        const int hi = N - qb0 - 4 * h;
-        bf16x8 pf[2][2], dsf[2][2];
+        constexpr int RPB = 16 / KS;              // S' registers per key block exponentiated beside one k-step
+        bf16x8 ga = lds_read_frag(Gt, roff[0]);
+        bf16x8 v0 = lds_read_frag(Vw, roff[0]), v1 = lds_read_frag(Vw, roff[0] + 32 * ROWB);
+        static_for<KS>([&](auto S) {
+            constexpr int sidx = decltype(S)::value;
+            bf16x8 gn = ga, v0n = v0, v1n = v1;
+            if constexpr (sidx + 1 < KS) {
+                gn = lds_read_frag(Gt, roff[sidx + 1]);
+                v0n = lds_read_frag(Vw, roff[sidx + 1]);
+                v1n = lds_read_frag(Vw, roff[sidx + 1] + 32 * ROWB);
+            }
+            mfma_vv(dpacc[0], ga, v0);
+            mfma_vv(dpacc[1], ga, v1);
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[kb][r] = __builtin_amdgcn_exp2f(sacc[kb][r] * c2);   // P[q][key]
+                for (int r = sidx * RPB; r < (sidx + 1) * RPB; ++r) {
+                    float sv = sacc[kb][r];
+                    pin(sv);                      // behind this step's MFMAs; S' retired a stage ago
+                    sacc[kb][r] = __builtin_amdgcn_exp2f(sv * c2);
+                }
+            keep_alive(ga); keep_alive(v0); keep_alive(v1);
+            ga = gn; v0 = v0n; v1 = v1n;
+            __builtin_amdgcn_sched_barrier(0);
+        });
         if (tail || diag) {          // wave-uniform and rare: a branch, not 64 selects per tile
+            const int hi = N - qb0 - 4 * h;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 const int lo = CAUSAL ? (kw0 + 32 * kb + ki) - qb0 - 4 * h : -1;
@@ -529,48 +537,80 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dkdv_kernel(BwdArgs p)
                 }
             }
         }
+        bf16x8 pf[2][2], dsf[2][2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dpacc[kb][r] = sacc[kb][r] * dpacc[kb][r];                 // dS[q][key]
-#pragma unroll
-            for (int sp = 0; sp < 2; ++sp) {
-                pf[kb][sp] = pack_acc(sacc[kb], sp);
-                dsf[kb][sp] = pack_acc(dpacc[kb], sp);
-            }
-        }
+            for (int sp = 0; sp < 2; ++sp) pf[kb][sp] = pack_acc(sacc[kb], sp);
 
-        // dV^T[dcol][key] += dO^T[dcol][q] P[q][key];  dK^T[dcol][key] += Q^T[dcol][q] dS[q][key]
-        // Group g = (dt, sp): four tr reads one group ahead of the four MFMAs that use them.
-#pragma unroll
-        for (int g = 0; g < 2 * DT; ++g) {
-            const int dt = g >> 1, sp = g & 1;
-            bf16x4 gn0 = gp0, gn1 = gp1, qn0 = qp0, qn1 = qp1;
-            if (g + 1 < 2 * DT) {
-                const int dtn = (g + 1) >> 1;
-                if ((g + 1) & 1) {
-                    gn0 = lds_read_tr_asm<GB + SPB>(lbase + toff[dtn][0]); gn1 = lds_read_tr_asm<GB + SPB>(lbase + toff[dtn][1]);
-                    qn0 = lds_read_tr_asm<QB + SPB>(lbase + toff[dtn][0]); qn1 = lds_read_tr_asm<QB + SPB>(lbase + toff[dtn][1]);
-                } else {
-                    gn0 = lds_read_tr_asm<GB>(lbase + toff[dtn][0]); gn1 = lds_read_tr_asm<GB>(lbase + toff[dtn][1]);
-                    qn0 = lds_read_tr_asm<QB>(lbase + toff[dtn][0]); qn1 = lds_read_tr_asm<QB>(lbase + toff[dtn][1]);
-                }
-                lds_tr_wait<4>(gp0, gp1, qp0, qp1);      // this group's four landed, next group's in flight
-            } else {
-                lds_tr_wait<0>(gp0, gp1, qp0, qp1);
+        // ---- stage C: dV^T[dcol][key] += dO^T[dcol][q] P[q][key], group g = (dt, sp), beside
+        // dS = P dP' of the finished dP' (settled first: it is only one stage old)
+        constexpr int QB = buf * BUFB + sh * HALFB, GB = QB + TILEB, SPB = 16 * ROWB;
+        const uint32_t lbase = (uint32_t)(uintptr_t)smem;
+        bf16x4 ta0 = lds_read_tr_asm<GB>(lbase + toff[0][0]), ta1 = lds_read_tr_asm<GB>(lbase + toff[0][1]);
+        mfma_vgpr_settle(dpacc[1]);
+        constexpr int RPC = 16 / (2 * DT);        // dP' registers per key block turned into dS beside one group
+        static_for<2 * DT>([&](auto G) {
+            constexpr int g = decltype(G)::value;
+            constexpr int dt = g >> 1, sp = g & 1;
+            bf16x4 tn0 = ta0, tn1 = ta1;
+            if constexpr (g + 1 < 2 * DT) {
+                constexpr int dtn = (g + 1) >> 1, spo = ((g + 1) & 1) * SPB;
+                tn0 = lds_read_tr_asm<GB + spo>(lbase + toff[dtn][0]);
+                tn1 = lds_read_tr_asm<GB + spo>(lbase + toff[dtn][1]);
+            } else {                                    // first Q^T fragment of stage D
+                tn0 = lds_read_tr_asm<QB>(lbase + toff[0][0]);
+                tn1 = lds_read_tr_asm<QB>(lbase + toff[0][1]);
             }
-            bf16x8 gT, qT;
+            lds_tr_wait2<2>(ta0, ta1);
+            bf16x8 gT;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                gT[e] = gp0[e]; gT[4 + e] = gp1[e];
-                qT[e] = qp0[e]; qT[4 + e] = qp1[e];
-            }
+            for (int e = 0; e < 4; ++e) { gT[e] = ta0[e]; gT[4 + e] = ta1[e]; }
             mfma32_acc(dvacc[0][dt], gT, pf[0][sp]);
             mfma32_acc(dvacc[1][dt], gT, pf[1][sp]);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = g * RPC; r < (g + 1) * RPC; ++r) {
+                    float dv = dpacc[kb][r];
+                    pin(dv);
+                    dpacc[kb][r] = sacc[kb][r] * dv;               // dS[q][key]
+                }
+            keep_alive(gT);
+            ta0 = tn0; ta1 = tn1;
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) dsf[kb][sp] = pack_acc(dpacc[kb], sp);
+
+        // ---- stage D: dK^T[dcol][key] += Q^T[dcol][q] dS[q][key]
+        static_for<2 * DT>([&](auto G) {
+            constexpr int g = decltype(G)::value;
+            constexpr int dt = g >> 1, sp = g & 1;
+            bf16x4 tn0 = ta0, tn1 = ta1;
+            if constexpr (g + 1 < 2 * DT) {
+                constexpr int dtn = (g + 1) >> 1, spo = ((g + 1) & 1) * SPB;
+                tn0 = lds_read_tr_asm<QB + spo>(lbase + toff[dtn][0]);
+                tn1 = lds_read_tr_asm<QB + spo>(lbase + toff[dtn][1]);
+                lds_tr_wait2<2>(ta0, ta1);
+            } else {
+                lds_tr_wait2<0>(ta0, ta1);
+            }
+            bf16x8 qT;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { qT[e] = ta0[e]; qT[4 + e] = ta1[e]; }
             mfma32_acc(dkacc[0][dt], qT, dsf[0][sp]);
             mfma32_acc(dkacc[1][dt], qT, dsf[1][sp]);
-            gp0 = gn0; gp1 = gn1; qp0 = qn0; qp1 = qn1;
-        }
+            ta0 = tn0; ta1 = tn1;
+        });
+    };
+    auto tile = [&](auto BUF, int t) {
+        constexpr int buf = decltype(BUF)::value;
+        if (t + 1 < tend) stage(t + 1, buf ^ 1);
+        sub(BUF, std::integral_constant<int, 0>{}, t);
+        sub(BUF, std::integral_constant<int, 1>{}, t);
         // hipcc may copy a pinned accumulator register (v_accvgpr_mov at the loop back-edge) without
         // knowing an MFMA is still writing it: let the last MFMAs of the tile retire first.
         mfma_acc_settle();
@@ -620,7 +660,7 @@ static hipError_t launch_bwd_one(const BwdArgs& a, hipStream_t stream)
     }
     const int nb = (a.N + kBwdRows - 1) / kBwdRows;
     constexpr int lds_dq = 2 * 2 * kDqKV * D * 2;
-    constexpr int lds_dk = kDkKeys * D * 2 + 2 * (2 * kDkQ * D * 2 + 256);
+    constexpr int lds_dk = kDkKeys * D * 2 + 2 * (2 * 2 * kDkQ * D * 2 + 512);
     static bool set_dq[64] = {}, set_dk[64] = {};
     e = ensure_dynamic_lds(fa2_bwd_dq_kernel<D, CAUSAL>, lds_dq, set_dq);
     if (e != hipSuccess) return e;

@@ -167,6 +167,13 @@ __device__ __forceinline__ void mfma_bagpr(f32x16& c, bf16x8 a)
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0"
                  : "+v"(c) : "v"(a), "i"(BLO), "i"(BLO + 3) : FA2_ACC_CLOBBERS);
 }
+// All-VGPR product issued from asm (c += a * b), for loops whose MFMA order is hand-placed: being
+// volatile it keeps its position among the other asm statements, which builtin MFMAs do not.
+__device__ __forceinline__ void mfma_vv(f32x16& c, bf16x8 a, bf16x8 b)
+{
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+
 // First product of a chain: c = a * a[BLO:BLO+3] (C = 0 inline constant: no zero-fill of the tile).
 template <int BLO>
 __device__ __forceinline__ void mfma_bagpr_init(f32x16& c, bf16x8 a)
