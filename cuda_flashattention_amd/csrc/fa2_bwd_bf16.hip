@@ -144,6 +144,13 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dq_kernel(BwdArgs p)
         Dq[qb] = p.D[(size_t)head * N + qld];
     });
     const float c2 = p.scale * kLog2e;
+    // -D of the lane's query row as a whole accumulator tile: the dP^T chains start from it, so
+    // dP' = dP - D comes out of the MFMA and dS = P dP' needs no subtraction.
+    f32x16 negD[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negD[qb][r] = -Dq[qb];
 
     // ---- LDS-DMA staging (as in fa2_fwd: one per-lane voffset, wave-uniform soffset, range-checked)
     const int drow = lane / CPR;
@@ -181,6 +188,9 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dq_kernel(BwdArgs p)
 
     // MASKED selects the variant that applies the key-tail / causal masks (a few tiles per
     // workgroup); the common variant carries no mask arithmetic at all.
+#ifdef FA2_DIAG_STAMPS
+    unsigned long long diag_t0 = 0, diag_t1 = 0, diag_comp = 0, diag_sync = 0;
+#endif
     auto tile_body = [&](auto BUF, auto MASKED_, int t) {
         constexpr int buf = decltype(BUF)::value;
         constexpr bool MASKED = decltype(MASKED_)::value;
@@ -193,56 +203,65 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dq_kernel(BwdArgs p)
         f32x16 sacc[2][2], dpacc[2][2];      // [qb][kb]: S^T[key][q], dP^T[key][q]
 
         // dS of registers [r0, r0 + n) of key block kb, both row blocks, in place in dpacc:
-        // P = exp2(c S - L), dS = P (dP - D).  pin() keeps the chunk behind the asm MFMAs issued
-        // before it in program order (the S/dP products of block kb are at least four MFMA issues
-        // old by then, i.e. retired), the sched_barrier after each call keeps it in front of the next.
+        // P = exp2(c S - L), dS = P dP'.  The chunk stays between the MFMA statements it is written
+        // between because those statements name the block's tiles as operands (fa2_common.h:
+        // mfma4_bagpr); the products it reads are at least four MFMA issues old by then, i.e. retired.
         auto ds_chunk = [&](int kb, int r0, int n) {
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
                 for (int r = r0; r < r0 + n; ++r) {
-                    float sv = sacc[qb][kb][r];
-                    pin(sv);
-                    float pr = __builtin_amdgcn_exp2f(sv * c2 - Lq[qb]);
+                    float pr = __builtin_amdgcn_exp2f(sacc[qb][kb][r] * c2 - Lq[qb]);
                     if constexpr (MASKED) {
                         const int key = key0 + 32 * kb + acc_row(r, h);
                         bool dead = key >= N;
                         if (CAUSAL) dead = dead || key > qrow[qb];
                         if (dead) pr = 0.0f;
                     }
-                    dpacc[qb][kb][r] = pr * (dpacc[qb][kb][r] - Dq[qb]);
+                    dpacc[qb][kb][r] = pr * dpacc[qb][kb][r];     // dP' already has -D in it
                 }
         };
 
         // ---- stage 1: S^T and dP^T, key block 0 then 1; the dS arithmetic of block 0 runs between
         // the MFMA groups of block 1
         constexpr int RP1 = 16 / KS;          // registers per row block handled beside one k-step
-        bf16x8 ka = lds_read_frag(Kt, roff[0]), va = lds_read_frag(Vt, roff[0]);
+        // K / V row fragments are read TWO k-steps ahead of their MFMAs: with one wave per SIMD an
+        // LDS round trip (> 100 cycles under load) is longer than one group of four MFMAs.
+        auto kfrag = [&](auto I_) {
+            constexpr int i = decltype(I_)::value;
+            return lds_read_frag(Kt, roff[i % KS] + (i / KS) * 32 * ROWB);
+        };
+        auto vfrag = [&](auto I_) {
+            constexpr int i = decltype(I_)::value;
+            return lds_read_frag(Vt, roff[i % KS] + (i / KS) * 32 * ROWB);
+        };
+        bf16x8 ka = kfrag(std::integral_constant<int, 0>{}), va = vfrag(std::integral_constant<int, 0>{});
+        bf16x8 kb1 = kfrag(std::integral_constant<int, 1>{}), vb1 = vfrag(std::integral_constant<int, 1>{});
         static_for<2 * KS>([&](auto I) {
             constexpr int i = decltype(I)::value;
             constexpr int kb = i / KS, sidx = i % KS;
-            bf16x8 kn = ka, vn = va;
-            if constexpr (i + 1 < 2 * KS) {
-                constexpr int o = ((i + 1) / KS) * 32 * ROWB;
-                kn = lds_read_frag(Kt, roff[(i + 1) % KS] + o);
-                vn = lds_read_frag(Vt, roff[(i + 1) % KS] + o);
+            bf16x8 kn = kb1, vn = vb1;
+            if constexpr (i + 2 < 2 * KS) {
+                kn = kfrag(std::integral_constant<int, i + 2>{});
+                vn = vfrag(std::integral_constant<int, i + 2>{});
             }
-            if constexpr (sidx == 0) {
-                mfma_bagpr_init<A_QF + (0 * KS + sidx) * 4>(sacc[0][kb], ka);
-                mfma_bagpr_init<A_QF + (1 * KS + sidx) * 4>(sacc[1][kb], ka);
-                mfma_bagpr_init<A_GF + (0 * KS + sidx) * 4>(dpacc[0][kb], va);
-                mfma_bagpr_init<A_GF + (1 * KS + sidx) * 4>(dpacc[1][kb], va);
-            } else {
-                mfma_bagpr<A_QF + (0 * KS + sidx) * 4>(sacc[0][kb], ka);
-                mfma_bagpr<A_QF + (1 * KS + sidx) * 4>(sacc[1][kb], ka);
-                mfma_bagpr<A_GF + (0 * KS + sidx) * 4>(dpacc[0][kb], va);
-                mfma_bagpr<A_GF + (1 * KS + sidx) * 4>(dpacc[1][kb], va);
-            }
+            if constexpr (sidx == 0)
+                mfma4_bagpr_init<A_QF + (0 * KS + sidx) * 4, A_QF + (1 * KS + sidx) * 4, A_GF + (0 * KS + sidx) * 4,
+                                 A_GF + (1 * KS + sidx) * 4>(sacc[0][kb], sacc[1][kb], dpacc[0][kb], dpacc[1][kb], ka, va,
+                                                             negD[0], negD[1]);
+            else if constexpr (kb == 1)
+                mfma4_bagpr<A_QF + (0 * KS + sidx) * 4, A_QF + (1 * KS + sidx) * 4, A_GF + (0 * KS + sidx) * 4,
+                            A_GF + (1 * KS + sidx) * 4>(sacc[0][1], sacc[1][1], dpacc[0][1], dpacc[1][1], ka, va,
+                                                        sacc[0][0], sacc[1][0], dpacc[0][0], dpacc[1][0]);
+            else
+                mfma4_bagpr<A_QF + (0 * KS + sidx) * 4, A_QF + (1 * KS + sidx) * 4, A_GF + (0 * KS + sidx) * 4,
+                            A_GF + (1 * KS + sidx) * 4>(sacc[0][kb], sacc[1][kb], dpacc[0][kb], dpacc[1][kb], ka, va);
+            if constexpr (kb == 1 && sidx == 0) thread4(sacc[0][0], sacc[1][0], dpacc[0][0], dpacc[1][0]);
             if constexpr (kb == 1) {
                 ds_chunk(0, sidx * RP1, RP1);
                 keep_alive(ka); keep_alive(va);
             }
-            ka = kn; va = vn;
+            ka = kb1; va = vb1; kb1 = kn; vb1 = vn;
             __builtin_amdgcn_sched_barrier(0);
         });
         bf16x8 dsf[2][2][2];                   // [qb][kb][sp]
@@ -251,8 +270,15 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dq_kernel(BwdArgs p)
             dsf[qb][0][0] = pack_acc(dpacc[qb][0], 0);
             dsf[qb][0][1] = pack_acc(dpacc[qb][0], 1);
         }
-        // first K^T fragment goes out, then the block-1 products get time to retire
-        bf16x4 ta0 = lds_read_tr_asm<KB>(lbase + toff[0][0]), ta1 = lds_read_tr_asm<KB>(lbase + toff[0][1]);
+        // K^T fragments are read two groups ahead; the block-1 products get time to retire meanwhile
+        auto tfrag = [&](auto G_, bf16x4& r0, bf16x4& r1) {
+            constexpr int g = decltype(G_)::value;
+            constexpr int kbn = g / (2 * DT), dtn = (g % (2 * DT)) >> 1, spn = g & 1;
+            lds_read_tr2_asm<KB + kbn * 32 * ROWB + spn * 16 * ROWB>(r0, r1, lbase + toff[dtn][0], lbase + toff[dtn][1]);
+        };
+        bf16x4 ta0, ta1, tb0, tb1;
+        tfrag(std::integral_constant<int, 0>{}, ta0, ta1);
+        tfrag(std::integral_constant<int, 1>{}, tb0, tb1);
         mfma_vgpr_settle(sacc[1][1]);
         __builtin_amdgcn_sched_barrier(0);
 
@@ -262,12 +288,11 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dq_kernel(BwdArgs p)
         static_for<4 * DT>([&](auto G) {
             constexpr int g = decltype(G)::value;
             constexpr int kb = g / (2 * DT), dt = (g % (2 * DT)) >> 1, sp = g & 1;
-            bf16x4 tn0 = ta0, tn1 = ta1;
-            if constexpr (g + 1 < 4 * DT) {
-                constexpr int kbn = (g + 1) / (2 * DT), dtn = ((g + 1) % (2 * DT)) >> 1, spn = (g + 1) & 1;
-                constexpr int o = KB + kbn * 32 * ROWB + spn * 16 * ROWB;
-                tn0 = lds_read_tr_asm<o>(lbase + toff[dtn][0]);
-                tn1 = lds_read_tr_asm<o>(lbase + toff[dtn][1]);
+            bf16x4 tn0 = tb0, tn1 = tb1;
+            if constexpr (g + 2 < 4 * DT) {
+                tfrag(std::integral_constant<int, g + 2>{}, tn0, tn1);
+                lds_tr_wait2<4>(ta0, ta1);          // groups g+1 and g+2 may still be in flight
+            } else if constexpr (g + 1 < 4 * DT) {
                 lds_tr_wait2<2>(ta0, ta1);
             } else {
                 lds_tr_wait2<0>(ta0, ta1);
@@ -275,9 +300,11 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dq_kernel(BwdArgs p)
             bf16x8 kT;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { kT[e] = ta0[e]; kT[4 + e] = ta1[e]; }
-            acc_mfma<A_DQ + (0 * DT + dt) * 16>(kT, dsf[0][kb][sp]);
-            acc_mfma<A_DQ + (1 * DT + dt) * 16>(kT, dsf[1][kb][sp]);
-            ta0 = tn0; ta1 = tn1;
+            if constexpr (kb == 0)
+                acc_mfma2<A_DQ + (0 * DT + dt) * 16, A_DQ + (1 * DT + dt) * 16>(kT, dsf[0][kb][sp], dsf[1][kb][sp],
+                                                                                sacc[0][1], sacc[1][1], dpacc[0][1], dpacc[1][1]);
+            else
+                acc_mfma2<A_DQ + (0 * DT + dt) * 16, A_DQ + (1 * DT + dt) * 16>(kT, dsf[0][kb][sp], dsf[1][kb][sp]);
             if constexpr (kb == 0) {
                 ds_chunk(1, (g % (2 * DT)) * RP2, RP2);
                 keep_alive(kT);
@@ -289,9 +316,17 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dq_kernel(BwdArgs p)
                     }
                 }
             }
+            ta0 = tb0; ta1 = tb1; tb0 = tn0; tb1 = tn1;
             __builtin_amdgcn_sched_barrier(0);
         });
+#ifdef FA2_DIAG_STAMPS
+        { unsigned long long ts; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts) :: "memory"); diag_t1 = ts; }
+#endif
         __syncthreads();     // drains this wave's DMA (vmcnt) and hands the buffers over
+#ifdef FA2_DIAG_STAMPS
+        { unsigned long long ts; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts) :: "memory");
+          diag_sync += ts - diag_t1; diag_comp += diag_t1 - diag_t0; diag_t0 = ts; }
+#endif
     };
 
     auto tile = [&](auto BUF, int t) {
@@ -301,10 +336,19 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dq_kernel(BwdArgs p)
         if (masked) tile_body(BUF, std::true_type{}, t);
         else tile_body(BUF, std::false_type{}, t);
     };
+#ifdef FA2_DIAG_STAMPS
+    { unsigned long long ts; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts) :: "memory"); diag_t0 = ts; }
+#endif
     for (int t = 0; t < tend; t += 2) {
         tile(std::integral_constant<int, 0>{}, t);
         tile(std::integral_constant<int, 1>{}, t + 1);
     }
+#ifdef FA2_DIAG_STAMPS
+    if (lane == 0) {      // diagnostic build only: cycle sums go to the row-constant workspace, which nothing else reads here
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.RC) + ((size_t)blockIdx.x * kDqWaves + wave) * 2;
+        dbg[0] = diag_comp; dbg[1] = diag_sync;
+    }
+#endif
 
     mfma_acc_settle();
     static_for<2>([&](auto QB) {

@@ -181,6 +181,87 @@ __device__ __forceinline__ void mfma_bagpr_init(f32x16& c, bf16x8 a)
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0"
                  : "=&v"(c) : "v"(a), "i"(BLO), "i"(BLO + 3) : FA2_ACC_CLOBBERS);
 }
+// One k-step of two products that share their streamed A operands, in ONE asm statement (every
+// asm boundary costs a pad s_nop from hipcc, and the loops that use these are issue-bound):
+//   s0 += ka * a[Q0..]   s1 += ka * a[Q1..]   d0 += va * a[G0..]   d1 += va * a[G1..]
+// The four `dep` tiles are not touched: naming them as read-write operands threads them through
+// this statement, so VALU code that consumes them cannot be scheduled above it and VALU code that
+// produces them cannot sink below the next such statement -- that is how arithmetic on a finished
+// tile is placed between the MFMA groups of the next one at no instruction cost.
+template <int Q0, int Q1, int G0, int G1>
+__device__ __forceinline__ void mfma4_bagpr(f32x16& s0, f32x16& s1, f32x16& d0, f32x16& d1, bf16x8 ka, bf16x8 va,
+                                            f32x16& dep0, f32x16& dep1, f32x16& dep2, f32x16& dep3)
+{
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %8, a[%c10:%c11], %0\n\t"
+                 "v_mfma_f32_32x32x16_bf16 %1, %8, a[%c12:%c13], %1\n\t"
+                 "v_mfma_f32_32x32x16_bf16 %2, %9, a[%c14:%c15], %2\n\t"
+                 "v_mfma_f32_32x32x16_bf16 %3, %9, a[%c16:%c17], %3"
+                 : "+v"(s0), "+v"(s1), "+v"(d0), "+v"(d1), "+v"(dep0), "+v"(dep1), "+v"(dep2), "+v"(dep3)
+                 : "v"(ka), "v"(va), "i"(Q0), "i"(Q0 + 3), "i"(Q1), "i"(Q1 + 3), "i"(G0), "i"(G0 + 3), "i"(G1), "i"(G1 + 3)
+                 : FA2_ACC_CLOBBERS);
+}
+template <int Q0, int Q1, int G0, int G1>
+__device__ __forceinline__ void mfma4_bagpr(f32x16& s0, f32x16& s1, f32x16& d0, f32x16& d1, bf16x8 ka, bf16x8 va)
+{
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %4, a[%c6:%c7], %0\n\t"
+                 "v_mfma_f32_32x32x16_bf16 %1, %4, a[%c8:%c9], %1\n\t"
+                 "v_mfma_f32_32x32x16_bf16 %2, %5, a[%c10:%c11], %2\n\t"
+                 "v_mfma_f32_32x32x16_bf16 %3, %5, a[%c12:%c13], %3"
+                 : "+v"(s0), "+v"(s1), "+v"(d0), "+v"(d1)
+                 : "v"(ka), "v"(va), "i"(Q0), "i"(Q0 + 3), "i"(Q1), "i"(Q1 + 3), "i"(G0), "i"(G0 + 3), "i"(G1), "i"(G1 + 3)
+                 : FA2_ACC_CLOBBERS);
+}
+// The same for the first k-step of the chains: s = ka * q (C = 0), d = va * g + c (C = a constant
+// tile, e.g. minus the row constant that would otherwise be subtracted element by element).
+template <int Q0, int Q1, int G0, int G1>
+__device__ __forceinline__ void mfma4_bagpr_init(f32x16& s0, f32x16& s1, f32x16& d0, f32x16& d1, bf16x8 ka, bf16x8 va,
+                                                 const f32x16& c0, const f32x16& c1)
+{
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %4, a[%c8:%c9], 0\n\t"
+                 "v_mfma_f32_32x32x16_bf16 %1, %4, a[%c10:%c11], 0\n\t"
+                 "v_mfma_f32_32x32x16_bf16 %2, %5, a[%c12:%c13], %6\n\t"
+                 "v_mfma_f32_32x32x16_bf16 %3, %5, a[%c14:%c15], %7"
+                 : "=&v"(s0), "=&v"(s1), "=&v"(d0), "=&v"(d1)
+                 : "v"(ka), "v"(va), "v"(c0), "v"(c1),
+                   "i"(Q0), "i"(Q0 + 3), "i"(Q1), "i"(Q1 + 3), "i"(G0), "i"(G0 + 3), "i"(G1), "i"(G1 + 3)
+                 : FA2_ACC_CLOBBERS);
+}
+// Threads four tiles through the asm order (see mfma4_bagpr) without doing anything.
+__device__ __forceinline__ void thread4(f32x16& a, f32x16& b, f32x16& c, f32x16& d)
+{
+    asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+// Two accumulations into asm-owned tiles that share their A operand: a[LO0..] += a * b0, a[LO1..] += a * b1.
+template <int LO0, int LO1>
+__device__ __forceinline__ void acc_mfma2(bf16x8 a, bf16x8 b0, bf16x8 b1)
+{
+    asm volatile("s_nop 0\n\tv_mfma_f32_32x32x16_bf16 a[%c3:%c4], %0, %1, a[%c3:%c4]\n\t"
+                 "v_mfma_f32_32x32x16_bf16 a[%c5:%c6], %0, %2, a[%c5:%c6]"
+                 : : "v"(a), "v"(b0), "v"(b1), "i"(LO0), "i"(LO0 + 15), "i"(LO1), "i"(LO1 + 15) : FA2_ACC_CLOBBERS);
+}
+// The same, threading four dependent tiles through the statement (see mfma4_bagpr).
+template <int LO0, int LO1>
+__device__ __forceinline__ void acc_mfma2(bf16x8 a, bf16x8 b0, bf16x8 b1, f32x16& dep0, f32x16& dep1, f32x16& dep2,
+                                          f32x16& dep3)
+{
+    asm volatile("s_nop 0\n\tv_mfma_f32_32x32x16_bf16 a[%c7:%c8], %4, %5, a[%c7:%c8]\n\t"
+                 "v_mfma_f32_32x32x16_bf16 a[%c9:%c10], %4, %6, a[%c9:%c10]"
+                 : "+v"(dep0), "+v"(dep1), "+v"(dep2), "+v"(dep3)
+                 : "v"(a), "v"(b0), "v"(b1), "i"(LO0), "i"(LO0 + 15), "i"(LO1), "i"(LO1 + 15) : FA2_ACC_CLOBBERS);
+}
+// Both halves of one transposed fragment in one statement.
+template <int IMM>
+__device__ __forceinline__ void lds_read_tr2_asm(bf16x4& r0, bf16x4& r1, uint32_t addr0, uint32_t addr1)
+{
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%4\n\tds_read_b64_tr_b16 %1, %3 offset:%4"
+                 : "=&v"(r0), "=&v"(r1) : "v"(addr0), "v"(addr1), "i"(IMM));
+}
+__device__ __forceinline__ void pin4(float& a, float& b, float& c, float& d)
+{
+    asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+__device__ __forceinline__ void pin2(float& a, float& b) { asm volatile("" : "+v"(a), "+v"(b)); }
+
 __device__ __forceinline__ void mfma_vgpr_settle(f32x16& c)
 {
     asm volatile("s_nop 15\n\ts_nop 3" : "+v"(c));
