@@ -211,6 +211,9 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dq_kernel(BwdArgs p)
             for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
                 for (int r = r0; r < r0 + n; ++r) {
+#ifdef FA2_ABL_NOVALU
+                    continue;
+#endif
                     float pr = __builtin_amdgcn_exp2f(sacc[qb][kb][r] * c2 - Lq[qb]);
                     if constexpr (MASKED) {
                         const int key = key0 + 32 * kb + acc_row(r, h);
@@ -241,10 +244,12 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dq_kernel(BwdArgs p)
             constexpr int i = decltype(I)::value;
             constexpr int kb = i / KS, sidx = i % KS;
             bf16x8 kn = kb1, vn = vb1;
+#ifndef FA2_ABL_NOLDS
             if constexpr (i + 2 < 2 * KS) {
                 kn = kfrag(std::integral_constant<int, i + 2>{});
                 vn = vfrag(std::integral_constant<int, i + 2>{});
             }
+#endif
             if constexpr (sidx == 0)
                 mfma4_bagpr_init<A_QF + (0 * KS + sidx) * 4, A_QF + (1 * KS + sidx) * 4, A_GF + (0 * KS + sidx) * 4,
                                  A_GF + (1 * KS + sidx) * 4>(sacc[0][kb], sacc[1][kb], dpacc[0][kb], dpacc[1][kb], ka, va,
@@ -289,7 +294,11 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dq_kernel(BwdArgs p)
             constexpr int g = decltype(G)::value;
             constexpr int kb = g / (2 * DT), dt = (g % (2 * DT)) >> 1, sp = g & 1;
             bf16x4 tn0 = tb0, tn1 = tb1;
+#ifdef FA2_ABL_NOLDS
+            if constexpr (false) {
+#else
             if constexpr (g + 2 < 4 * DT) {
+#endif
                 tfrag(std::integral_constant<int, g + 2>{}, tn0, tn1);
                 lds_tr_wait2<4>(ta0, ta1);          // groups g+1 and g+2 may still be in flight
             } else if constexpr (g + 1 < 4 * DT) {
@@ -534,8 +543,7 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dkdv_kernel(BwdArgs p)
             constexpr int sidx = decltype(S)::value;
             bf16x8 qn = qa;
             if constexpr (sidx + 1 < KS) qn = lds_read_frag(Qt, roff[sidx + 1]);
-            mfma_vv(sacc[0], qa, kf[0][sidx]);
-            mfma_vv(sacc[1], qa, kf[1][sidx]);
+            mfma2_vv(sacc[0], sacc[1], qa, kf[0][sidx], kf[1][sidx]);
             qa = qn;
         });
         __builtin_amdgcn_sched_barrier(0);
@@ -555,20 +563,17 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dkdv_kernel(BwdArgs p)
                 v0n = lds_read_frag(Vw, roff[sidx + 1]);
                 v1n = lds_read_frag(Vw, roff[sidx + 1] + 32 * ROWB);
             }
-            mfma_vv(dpacc[0], ga, v0);
-            mfma_vv(dpacc[1], ga, v1);
+            mfma2_vv(dpacc[0], dpacc[1], ga, v0, v1, sacc[0], sacc[1]);     // S' tiles threaded through: see below
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = sidx * RPB; r < (sidx + 1) * RPB; ++r) {
-                    float sv = sacc[kb][r];
-                    pin(sv);                      // behind this step's MFMAs; S' retired a stage ago
-                    sacc[kb][r] = __builtin_amdgcn_exp2f(sv * c2);
-                }
+                for (int r = sidx * RPB; r < (sidx + 1) * RPB; ++r)    // behind this step's MFMAs; S' retired a stage ago
+                    sacc[kb][r] = __builtin_amdgcn_exp2f(sacc[kb][r] * c2);
             keep_alive(ga); keep_alive(v0); keep_alive(v1);
             ga = gn; v0 = v0n; v1 = v1n;
             __builtin_amdgcn_sched_barrier(0);
         });
+        thread4(sacc[0], sacc[1], dpacc[0], dpacc[1]);
         if (tail || diag) {          // wave-uniform and rare: a branch, not 64 selects per tile
             const int hi = N - qb0 - 4 * h;
 #pragma unroll
@@ -591,7 +596,8 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dkdv_kernel(BwdArgs p)
         // dS = P dP' of the finished dP' (settled first: it is only one stage old)
         constexpr int QB = buf * BUFB + sh * HALFB, GB = QB + TILEB, SPB = 16 * ROWB;
         const uint32_t lbase = (uint32_t)(uintptr_t)smem;
-        bf16x4 ta0 = lds_read_tr_asm<GB>(lbase + toff[0][0]), ta1 = lds_read_tr_asm<GB>(lbase + toff[0][1]);
+        bf16x4 ta0, ta1;
+        lds_read_tr2_asm<GB>(ta0, ta1, lbase + toff[0][0], lbase + toff[0][1]);
         mfma_vgpr_settle(dpacc[1]);
         constexpr int RPC = 16 / (2 * DT);        // dP' registers per key block turned into dS beside one group
         static_for<2 * DT>([&](auto G) {
@@ -600,30 +606,24 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dkdv_kernel(BwdArgs p)
             bf16x4 tn0 = ta0, tn1 = ta1;
             if constexpr (g + 1 < 2 * DT) {
                 constexpr int dtn = (g + 1) >> 1, spo = ((g + 1) & 1) * SPB;
-                tn0 = lds_read_tr_asm<GB + spo>(lbase + toff[dtn][0]);
-                tn1 = lds_read_tr_asm<GB + spo>(lbase + toff[dtn][1]);
+                lds_read_tr2_asm<GB + spo>(tn0, tn1, lbase + toff[dtn][0], lbase + toff[dtn][1]);
             } else {                                    // first Q^T fragment of stage D
-                tn0 = lds_read_tr_asm<QB>(lbase + toff[0][0]);
-                tn1 = lds_read_tr_asm<QB>(lbase + toff[0][1]);
+                lds_read_tr2_asm<QB>(tn0, tn1, lbase + toff[0][0], lbase + toff[0][1]);
             }
             lds_tr_wait2<2>(ta0, ta1);
             bf16x8 gT;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { gT[e] = ta0[e]; gT[4 + e] = ta1[e]; }
-            mfma32_acc(dvacc[0][dt], gT, pf[0][sp]);
-            mfma32_acc(dvacc[1][dt], gT, pf[1][sp]);
+            mfma2_acc(dvacc[0][dt], dvacc[1][dt], gT, pf[0][sp], pf[1][sp], dpacc[0], dpacc[1]);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = g * RPC; r < (g + 1) * RPC; ++r) {
-                    float dv = dpacc[kb][r];
-                    pin(dv);
-                    dpacc[kb][r] = sacc[kb][r] * dv;               // dS[q][key]
-                }
+                for (int r = g * RPC; r < (g + 1) * RPC; ++r) dpacc[kb][r] = sacc[kb][r] * dpacc[kb][r];   // dS[q][key]
             keep_alive(gT);
             ta0 = tn0; ta1 = tn1;
             __builtin_amdgcn_sched_barrier(0);
         });
+        thread4(sacc[0], sacc[1], dpacc[0], dpacc[1]);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -636,8 +636,7 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dkdv_kernel(BwdArgs p)
             bf16x4 tn0 = ta0, tn1 = ta1;
             if constexpr (g + 1 < 2 * DT) {
                 constexpr int dtn = (g + 1) >> 1, spo = ((g + 1) & 1) * SPB;
-                tn0 = lds_read_tr_asm<QB + spo>(lbase + toff[dtn][0]);
-                tn1 = lds_read_tr_asm<QB + spo>(lbase + toff[dtn][1]);
+                lds_read_tr2_asm<QB + spo>(tn0, tn1, lbase + toff[dtn][0], lbase + toff[dtn][1]);
                 lds_tr_wait2<2>(ta0, ta1);
             } else {
                 lds_tr_wait2<0>(ta0, ta1);
@@ -645,8 +644,7 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dkdv_kernel(BwdArgs p)
             bf16x8 qT;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { qT[e] = ta0[e]; qT[4 + e] = ta1[e]; }
-            mfma32_acc(dkacc[0][dt], qT, dsf[0][sp]);
-            mfma32_acc(dkacc[1][dt], qT, dsf[1][sp]);
+            mfma2_acc(dkacc[0][dt], dkacc[1][dt], qT, dsf[0][sp], dsf[1][sp]);
             ta0 = tn0; ta1 = tn1;
         });
     };

@@ -174,6 +174,30 @@ __device__ __forceinline__ void mfma_vv(f32x16& c, bf16x8 a, bf16x8 b)
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 
+// Two all-VGPR products sharing their A operand in one statement: c0 += a * b0, c1 += a * b1.
+__device__ __forceinline__ void mfma2_vv(f32x16& c0, f32x16& c1, bf16x8 a, bf16x8 b0, bf16x8 b1)
+{
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %2, %4, %1"
+                 : "+v"(c0), "+v"(c1) : "v"(a), "v"(b0), "v"(b1));
+}
+// The same, threading two finished tiles through the statement (see mfma4_bagpr).
+__device__ __forceinline__ void mfma2_vv(f32x16& c0, f32x16& c1, bf16x8 a, bf16x8 b0, bf16x8 b1, f32x16& dep0, f32x16& dep1)
+{
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %4, %5, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %4, %6, %1"
+                 : "+v"(c0), "+v"(c1), "+v"(dep0), "+v"(dep1) : "v"(a), "v"(b0), "v"(b1));
+}
+// Two accumulations into hipcc-allocated AGPR tiles sharing their A operand (see mfma32_acc).
+__device__ __forceinline__ void mfma2_acc(f32x16& c0, f32x16& c1, bf16x8 a, bf16x8 b0, bf16x8 b1)
+{
+    asm volatile("s_nop 0\n\tv_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %2, %4, %1"
+                 : "+a"(c0), "+a"(c1) : "v"(a), "v"(b0), "v"(b1));
+}
+__device__ __forceinline__ void mfma2_acc(f32x16& c0, f32x16& c1, bf16x8 a, bf16x8 b0, bf16x8 b1, f32x16& dep0, f32x16& dep1)
+{
+    asm volatile("s_nop 0\n\tv_mfma_f32_32x32x16_bf16 %0, %4, %5, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %4, %6, %1"
+                 : "+a"(c0), "+a"(c1), "+v"(dep0), "+v"(dep1) : "v"(a), "v"(b0), "v"(b1));
+}
+
 // First product of a chain: c = a * a[BLO:BLO+3] (C = 0 inline constant: no zero-fill of the tile).
 template <int BLO>
 __device__ __forceinline__ void mfma_bagpr_init(f32x16& c, bf16x8 a)
