@@ -250,6 +250,42 @@ __device__ __forceinline__ void mfma4_bagpr_init(f32x16& s0, f32x16& s1, f32x16&
                    "i"(Q0), "i"(Q0 + 3), "i"(Q1), "i"(Q1 + 3), "i"(G0), "i"(G0 + 3), "i"(G1), "i"(G1 + 3)
                  : FA2_ACC_CLOBBERS);
 }
+// Two products sharing the streamed A operand, B operands resident in AGPRs: s0 += a * a[Q0..], s1 += a * a[Q1..].
+template <int Q0, int Q1>
+__device__ __forceinline__ void mfma2_bagpr(f32x16& s0, f32x16& s1, bf16x8 a)
+{
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, a[%c3:%c4], %0\n\tv_mfma_f32_32x32x16_bf16 %1, %2, a[%c5:%c6], %1"
+                 : "+v"(s0), "+v"(s1) : "v"(a), "i"(Q0), "i"(Q0 + 3), "i"(Q1), "i"(Q1 + 3) : FA2_ACC_CLOBBERS);
+}
+template <int Q0, int Q1>
+__device__ __forceinline__ void mfma2_bagpr_init(f32x16& s0, f32x16& s1, bf16x8 a)
+{
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, a[%c3:%c4], 0\n\tv_mfma_f32_32x32x16_bf16 %1, %2, a[%c5:%c6], 0"
+                 : "=&v"(s0), "=&v"(s1) : "v"(a), "i"(Q0), "i"(Q0 + 3), "i"(Q1), "i"(Q1 + 3) : FA2_ACC_CLOBBERS);
+}
+__device__ __forceinline__ void thread2(f32x16& a, f32x16& b) { asm volatile("" : "+v"(a), "+v"(b)); }
+// acc_mfma2 threading TWO dependent tiles.
+template <int LO0, int LO1>
+__device__ __forceinline__ void acc_mfma2(bf16x8 a, bf16x8 b0, bf16x8 b1, f32x16& dep0, f32x16& dep1)
+{
+    asm volatile("s_nop 0\n\tv_mfma_f32_32x32x16_bf16 a[%c5:%c6], %2, %3, a[%c5:%c6]\n\t"
+                 "v_mfma_f32_32x32x16_bf16 a[%c7:%c8], %2, %4, a[%c7:%c8]"
+                 : "+v"(dep0), "+v"(dep1)
+                 : "v"(a), "v"(b0), "v"(b1), "i"(LO0), "i"(LO0 + 15), "i"(LO1), "i"(LO1 + 15) : FA2_ACC_CLOBBERS);
+}
+// acc_mfma2 threading two tiles and two scalars (running sums that must not be deferred).
+template <int LO0, int LO1>
+__device__ __forceinline__ void acc_mfma2(bf16x8 a, bf16x8 b0, bf16x8 b1, f32x16& dep0, f32x16& dep1, float& f0, float& f1)
+{
+    asm volatile("s_nop 0\n\tv_mfma_f32_32x32x16_bf16 a[%c7:%c8], %4, %5, a[%c7:%c8]\n\t"
+                 "v_mfma_f32_32x32x16_bf16 a[%c9:%c10], %4, %6, a[%c9:%c10]"
+                 : "+v"(dep0), "+v"(dep1), "+v"(f0), "+v"(f1)
+                 : "v"(a), "v"(b0), "v"(b1), "i"(LO0), "i"(LO0 + 15), "i"(LO1), "i"(LO1 + 15) : FA2_ACC_CLOBBERS);
+}
+__device__ __forceinline__ void thread2f(f32x16& a, f32x16& b, float& f0, float& f1)
+{
+    asm volatile("" : "+v"(a), "+v"(b), "+v"(f0), "+v"(f1));
+}
 // Threads four tiles through the asm order (see mfma4_bagpr) without doing anything.
 __device__ __forceinline__ void thread4(f32x16& a, f32x16& b, f32x16& c, f32x16& d)
 {
