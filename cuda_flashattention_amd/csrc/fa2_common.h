@@ -264,6 +264,22 @@ __device__ __forceinline__ void mfma2_bagpr_init(f32x16& s0, f32x16& s1, bf16x8 
                  : "=&v"(s0), "=&v"(s1) : "v"(a), "i"(Q0), "i"(Q0 + 3), "i"(Q1), "i"(Q1 + 3) : FA2_ACC_CLOBBERS);
 }
 __device__ __forceinline__ void thread2(f32x16& a, f32x16& b) { asm volatile("" : "+v"(a), "+v"(b)); }
+// mfma2_bagpr threading two finished tiles (read beside this statement) and two scalars (partial
+// results that must be complete before the next statement).
+template <int Q0, int Q1>
+__device__ __forceinline__ void mfma2_bagpr(f32x16& s0, f32x16& s1, bf16x8 a, f32x16& dep0, f32x16& dep1, float& f0, float& f1)
+{
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %6, a[%c7:%c8], %0\n\tv_mfma_f32_32x32x16_bf16 %1, %6, a[%c9:%c10], %1"
+                 : "+v"(s0), "+v"(s1), "+v"(dep0), "+v"(dep1), "+v"(f0), "+v"(f1)
+                 : "v"(a), "i"(Q0), "i"(Q0 + 3), "i"(Q1), "i"(Q1 + 3) : FA2_ACC_CLOBBERS);
+}
+template <int Q0, int Q1>
+__device__ __forceinline__ void mfma2_bagpr_init(f32x16& s0, f32x16& s1, bf16x8 a, f32x16& dep0, f32x16& dep1, float& f0, float& f1)
+{
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %6, a[%c7:%c8], 0\n\tv_mfma_f32_32x32x16_bf16 %1, %6, a[%c9:%c10], 0"
+                 : "=&v"(s0), "=&v"(s1), "+v"(dep0), "+v"(dep1), "+v"(f0), "+v"(f1)
+                 : "v"(a), "i"(Q0), "i"(Q0 + 3), "i"(Q1), "i"(Q1 + 3) : FA2_ACC_CLOBBERS);
+}
 // acc_mfma2 threading TWO dependent tiles.
 template <int LO0, int LO1>
 __device__ __forceinline__ void acc_mfma2(bf16x8 a, bf16x8 b0, bf16x8 b1, f32x16& dep0, f32x16& dep1)

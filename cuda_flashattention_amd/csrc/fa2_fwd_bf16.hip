@@ -180,19 +180,33 @@ __global__ void __launch_bounds__(256, 1) fa2_fwd_bf16_kernel(FwdArgs p)
 
     // A stage: S^T of the 32 keys whose K rows start KOFF bytes into the K region, masked.  key0 is the
     // index of the first of those keys.
-    auto stage_a = [&](auto KOFF_, int key0, f32x16 (&snext)[2]) {
+    // It also takes the in-lane maximum of the CURRENT half-tile (scur) between its MFMA statements
+    // (rmax[qb], over this lane's 16 keys): scur is threaded through the statements so the partial
+    // maxima sit beside the MFMAs instead of after them.
+    float rmax[2] = {-INFINITY, -INFINITY};
+    auto stage_a = [&](auto KOFF_, int key0, f32x16 (&snext)[2], bool with_max) {
         constexpr int KOFF = decltype(KOFF_)::value;
         const char* Kt = smem + KOFF;
+        constexpr int RPS = 16 / KS;                 // scur registers folded into the maximum per k-step
         bf16x8 ka = lds_read_frag(Kt, roff[0]);
         bf16x8 kb1 = lds_read_frag(Kt, roff[1]);
+        rmax[0] = -INFINITY; rmax[1] = -INFINITY;
         static_for<KS>([&](auto S) {
             constexpr int sidx = decltype(S)::value;
             bf16x8 kn = kb1;
             if constexpr (sidx + 2 < KS) kn = lds_read_frag(Kt, roff[sidx + 2]);
             if constexpr (sidx == 0)
-                mfma2_bagpr_init<A_QF + (0 * KS + sidx) * 4, A_QF + (1 * KS + sidx) * 4>(snext[0], snext[1], ka);
+                mfma2_bagpr_init<A_QF + (0 * KS + sidx) * 4, A_QF + (1 * KS + sidx) * 4>(snext[0], snext[1], ka, scur[0], scur[1],
+                                                                                         rmax[0], rmax[1]);
             else
-                mfma2_bagpr<A_QF + (0 * KS + sidx) * 4, A_QF + (1 * KS + sidx) * 4>(snext[0], snext[1], ka);
+                mfma2_bagpr<A_QF + (0 * KS + sidx) * 4, A_QF + (1 * KS + sidx) * 4>(snext[0], snext[1], ka, scur[0], scur[1],
+                                                                                    rmax[0], rmax[1]);
+            if (with_max) {
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                    for (int r = sidx * RPS; r < (sidx + 1) * RPS; ++r) rmax[qb] = fmaxf(rmax[qb], scur[qb][r]);
+            }
             ka = kb1; kb1 = kn;
         });
         const bool tail = key0 + 32 > Nk;
@@ -226,10 +240,7 @@ __global__ void __launch_bounds__(256, 1) fa2_fwd_bf16_kernel(FwdArgs p)
         bool need[2];
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
-            float mx = scur[qb][0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, scur[qb][r]);
-            mx = half_max(mx) * p.scale;
+            float mx = half_max(rmax[qb]) * p.scale;      // rmax: taken beside the S^T MFMAs (stage_a)
             // Lazy reference max: the rows of this block move to their current max only when some
             // row's max has grown by more than kRescaleThr since the reference was taken (or has
             // no reference yet).  In between, P = exp(s - m_ref) may exceed 1 (by at most
@@ -306,8 +317,12 @@ __global__ void __launch_bounds__(256, 1) fa2_fwd_bf16_kernel(FwdArgs p)
         for (int sp = 0; sp < 2; ++sp)
 #pragma unroll
             for (int e = 0; e < 8; ++e) pprev[qb][sp][e] = (__bf16)0.0f;
-    stage_a(std::integral_constant<int, 0>{}, 0, scur);
-    mfma_vgpr_settle(scur[1]);
+    {
+        f32x16 s0[2];
+        stage_a(std::integral_constant<int, 0>{}, 0, s0, false);
+        mfma_vgpr_settle(s0[1]);
+        scur[0] = s0[0]; scur[1] = s0[1];
+    }
 
     // One 64-key tile T living in ring buffer B (= T mod 3):
     //   step 1 (u = 2T)  : A on K[T] second half       ; X(u) ; B on V[T-1] second half (buffer B+2)
@@ -317,12 +332,12 @@ __global__ void __launch_bounds__(256, 1) fa2_fwd_bf16_kernel(FwdArgs p)
         constexpr int B = decltype(B_)::value;
         constexpr int B1 = (B + 1) % kFwdBufs, B2 = (B + 2) % kFwdBufs;
         f32x16 snext[2];
-        stage_a(std::integral_constant<int, B * TILEB + HALFB>{}, T * kFwdKV + 32, snext);
+        stage_a(std::integral_constant<int, B * TILEB + HALFB>{}, T * kFwdKV + 32, snext, true);
         stage_xb(std::integral_constant<int, B2 * TILEB + HALFB>{});
         scur[0] = snext[0]; scur[1] = snext[1];
         __syncthreads();
         stage(T + 2, B2);
-        stage_a(std::integral_constant<int, B1 * TILEB>{}, (T + 1) * kFwdKV, snext);
+        stage_a(std::integral_constant<int, B1 * TILEB>{}, (T + 1) * kFwdKV, snext, true);
         stage_xb(std::integral_constant<int, B * TILEB>{});
         scur[0] = snext[0]; scur[1] = snext[1];
     };
