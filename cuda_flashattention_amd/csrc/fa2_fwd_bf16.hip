@@ -201,7 +201,11 @@ __global__ void __launch_bounds__(256, 1) fa2_fwd_bf16_kernel(FwdArgs p)
             else
                 mfma2_bagpr<A_QF + (0 * KS + sidx) * 4, A_QF + (1 * KS + sidx) * 4>(snext[0], snext[1], ka, scur[0], scur[1],
                                                                                     rmax[0], rmax[1]);
+#ifdef FA2_ABL_NOMAX
+            if (false) {
+#else
             if (with_max) {
+#endif
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
@@ -264,7 +268,11 @@ __global__ void __launch_bounds__(256, 1) fa2_fwd_bf16_kernel(FwdArgs p)
             constexpr int g = decltype(G)::value;
             constexpr int dt = g >> 1, sp = g & 1;
             bf16x4 vn0 = va0, vn1 = va1;
+#ifdef FA2_ABL_NOTR
+            if constexpr (false) {
+#else
             if constexpr (g + 1 < NG) {
+#endif
                 constexpr int dtn = (g + 1) >> 1;
                 constexpr int spo = ((g + 1) & 1) * 16 * ROWB;
                 lds_read_tr2_asm<VOFF + spo>(vn0, vn1, lbase + toff[dtn][0], lbase + toff[dtn][1]);
@@ -284,6 +292,9 @@ __global__ void __launch_bounds__(256, 1) fa2_fwd_bf16_kernel(FwdArgs p)
             for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
                 for (int r = g * RPG; r < (g + 1) * RPG; ++r) {
+#ifdef FA2_ABL_NOEXP
+                    continue;
+#endif
                     const float e = __builtin_amdgcn_exp2f(scur[qb][r] * c2 - mb[qb]);
                     scur[qb][r] = e;
                     psum[qb] += e;
