@@ -298,7 +298,8 @@ __device__ __forceinline__ void acc_mfma2(bf16x8 a, bf16x8 b0, bf16x8 b1, f32x16
                  : "+v"(dep0), "+v"(dep1), "+v"(f0), "+v"(f1)
                  : "v"(a), "v"(b0), "v"(b1), "i"(LO0), "i"(LO0 + 15), "i"(LO1), "i"(LO1 + 15) : FA2_ACC_CLOBBERS);
 }
-__device__ __forceinline__ void thread2f(f32x16& a, f32x16& b, float& f0, float& f1)
+template <typename F>
+__device__ __forceinline__ void thread2f(f32x16& a, f32x16& b, F& f0, F& f1)
 {
     asm volatile("" : "+v"(a), "+v"(b), "+v"(f0), "+v"(f1));
 }
@@ -325,6 +326,49 @@ __device__ __forceinline__ void acc_mfma2(bf16x8 a, bf16x8 b0, bf16x8 b1, f32x16
                  : "+v"(dep0), "+v"(dep1), "+v"(dep2), "+v"(dep3)
                  : "v"(a), "v"(b0), "v"(b1), "i"(LO0), "i"(LO0 + 15), "i"(LO1), "i"(LO1 + 15) : FA2_ACC_CLOBBERS);
 }
+// One PV group of the forward kernel in ONE statement: the two transposed reads of the NEXT group's
+// V^T fragment (n0, n1), the wait that leaves exactly those two in flight (so the current fragment
+// `a`, read one group earlier, has landed), and the two accumulations a[LO0..] += a * b0,
+// a[LO1..] += a * b1.  No pad s_nop: none of a, b0, b1 may have been written by a VALU instruction
+// within the two instructions before this statement (they come from LDS and from the previous
+// step's packing).  dep0/dep1/f0/f1 are threaded through (see mfma4_bagpr).
+template <int IMM, int LO0, int LO1, typename F>
+__device__ __forceinline__ void pv_group_next(bf16x4& n0, bf16x4& n1, uint32_t addr0, uint32_t addr1, bf16x8 a, bf16x8 b0,
+                                              bf16x8 b1, f32x16& dep0, f32x16& dep1, F& f0, F& f1)
+{
+    asm volatile("ds_read_b64_tr_b16 %0, %6 offset:%c8\n\tds_read_b64_tr_b16 %1, %7 offset:%c8\n\t"
+                 "s_waitcnt lgkmcnt(2)\n\t"
+                 "v_mfma_f32_32x32x16_bf16 a[%c12:%c13], %9, %10, a[%c12:%c13]\n\t"
+                 "v_mfma_f32_32x32x16_bf16 a[%c14:%c15], %9, %11, a[%c14:%c15]"
+                 : "=&v"(n0), "=&v"(n1), "+v"(dep0), "+v"(dep1), "+v"(f0), "+v"(f1)
+                 : "v"(addr0), "v"(addr1), "i"(IMM), "v"(a), "v"(b0), "v"(b1), "i"(LO0), "i"(LO0 + 15), "i"(LO1), "i"(LO1 + 15)
+                 : FA2_ACC_CLOBBERS);
+}
+// The last group of a stage: nothing further to read, wait for everything.
+template <int LO0, int LO1, typename F>
+__device__ __forceinline__ void pv_group_last(bf16x8 a, bf16x8 b0, bf16x8 b1, f32x16& dep0, f32x16& dep1, F& f0, F& f1)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                 "v_mfma_f32_32x32x16_bf16 a[%c7:%c8], %4, %5, a[%c7:%c8]\n\t"
+                 "v_mfma_f32_32x32x16_bf16 a[%c9:%c10], %4, %6, a[%c9:%c10]"
+                 : "+v"(dep0), "+v"(dep1), "+v"(f0), "+v"(f1)
+                 : "v"(a), "v"(b0), "v"(b1), "i"(LO0), "i"(LO0 + 15), "i"(LO1), "i"(LO1 + 15) : FA2_ACC_CLOBBERS);
+}
+// acc += p.lo + p.hi for a packed bf16 pair (v_dot2c_f32_bf16 against a pair of ones): the running
+// row sum is taken over the ROUNDED probabilities, the same values the PV product consumes.
+__device__ __forceinline__ void sum_bf16_pair(float& acc, uint32_t p)
+{
+    asm("v_dot2c_f32_bf16 %0, 0x3f803f80, %1" : "+v"(acc) : "v"(p));
+}
+// Two floats -> one packed bf16 pair (v_cvt_pk_bf16_f32, round to nearest even).
+__device__ __forceinline__ uint32_t pack_bf16_pair(float lo, float hi)
+{
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    const bf16x2_t v = __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t);
+    return __builtin_bit_cast(uint32_t, v);
+}
+
 // Both halves of one transposed fragment in one statement.
 template <int IMM>
 __device__ __forceinline__ void lds_read_tr2_asm(bf16x4& r0, bf16x4& r1, uint32_t addr0, uint32_t addr1)

@@ -48,6 +48,11 @@ constexpr int kFwdBufs = 3;                 // LDS ring depth
 constexpr float kRescaleThr = 6.0f;         // natural-log units of the scaled score
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+#ifdef FA2_SUM_PK
+typedef f32x2 LSum;
+#else
+typedef float LSum;
+#endif
 
 template <int D, bool CAUSAL, bool STATE>
 __global__ void __launch_bounds__(256, 1) fa2_fwd_bf16_kernel(FwdArgs p)
@@ -115,7 +120,15 @@ __global__ void __launch_bounds__(256, 1) fa2_fwd_bf16_kernel(FwdArgs p)
 
     // ---- running state.  O^T lives in literal AGPRs (fa2_common.h: acc_*): tile (qb, dt) is
     // a[(qb * DT + dt) * 16 .. +15], register 4g + e of it is O[q][32 dt + 8 g + 4 h + e].
-    float m_run[2], l_run[2];
+    // m_run: the reference maximum (natural units), mb = m_run * log2(e) (0 while -inf), thr = the raw
+    // (unscaled) score above which a row asks for a new reference; l_run: this lane's share of the row sum.
+    const float inv_scale = 1.0f / p.scale;
+    float m_run[2], mb[2], thr[2];
+#ifdef FA2_SUM_PK
+    f32x2 l_run[2];
+#else
+    float l_run[2];
+#endif
     static_for<2>([&](auto QB) {
         constexpr int qb = decltype(QB)::value;
         if (STATE && p.resume) {
@@ -130,11 +143,15 @@ __global__ void __launch_bounds__(256, 1) fa2_fwd_bf16_kernel(FwdArgs p)
                 });
             });
             m_run[qb] = p.M[(size_t)head * Nq + qld];
-            l_run[qb] = h == 0 ? p.L[(size_t)head * Nq + qld] : 0.0f;
+            l_run[qb] = LSum{h == 0 ? p.L[(size_t)head * Nq + qld] : 0.0f};
+            mb[qb] = m_run[qb] == -INFINITY ? 0.0f : m_run[qb] * kLog2e;
+            thr[qb] = (m_run[qb] + kRescaleThr) * inv_scale;
         } else {
             static_for<16 * DT>([&](auto R) { acc_write<A_O + qb * DT * 16 + decltype(R)::value>(0.0f); });
             m_run[qb] = -INFINITY;
-            l_run[qb] = 0.0f;
+            l_run[qb] = LSum{0.0f};
+            mb[qb] = 0.0f;
+            thr[qb] = -INFINITY;
         }
     });
 
@@ -201,11 +218,7 @@ __global__ void __launch_bounds__(256, 1) fa2_fwd_bf16_kernel(FwdArgs p)
             else
                 mfma2_bagpr<A_QF + (0 * KS + sidx) * 4, A_QF + (1 * KS + sidx) * 4>(snext[0], snext[1], ka, scur[0], scur[1],
                                                                                     rmax[0], rmax[1]);
-#ifdef FA2_ABL_NOMAX
-            if (false) {
-#else
             if (with_max) {
-#endif
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
@@ -230,89 +243,97 @@ __global__ void __launch_bounds__(256, 1) fa2_fwd_bf16_kernel(FwdArgs p)
         }
     };
 
-    // X + B stages of one half-tile step: decide the new running max of half-tile u (scur), then
-    // O^T += V^T P^T of half-tile u-1 (V rows start VOFF bytes into the V region, P = pprev) with the
-    // exponentials of u issued between its MFMA groups; finally the (rare) rescale and the
-    // rotation pprev <- P(u).
+    // X + B stages of one half-tile step: O^T += V^T P^T of half-tile u-1 (V rows start VOFF bytes
+    // into the V region, P = pprev) with the exponentials of half-tile u (scur) issued between its
+    // MFMA groups, packed to bf16 as they appear (they are the next step's pprev) and summed from the
+    // packed values.  The running maximum is a LAZY reference: the rows of a block move to their
+    // current maximum only when some row's score has risen more than kRescaleThr above its reference
+    // (or has no reference yet) -- one compare per row block on the common path.  In between,
+    // P = exp(s - m_ref) may exceed 1 (by at most e^kRescaleThr): harmless in fp32 sums and in bf16 P,
+    // whose relative precision does not depend on magnitude -- and O, l and L come out the same.
     auto stage_xb = [&](auto VOFF_) {
         constexpr int VOFF = decltype(VOFF_)::value;
         // first V^T fragment goes out before the arithmetic
         bf16x4 va0, va1;
         lds_read_tr2_asm<VOFF>(va0, va1, lbase + toff[0][0], lbase + toff[0][1]);
 
-        float alpha[2], mb[2], psum[2];
-        bool need[2];
+        float alpha[2] = {1.0f, 1.0f};
+        bool need[2] = {false, false};
+        if (__any(rmax[0] > thr[0] || rmax[1] > thr[1])) {      // rmax: taken beside the S^T MFMAs (stage_a)
+            asm volatile("; fa2-cold: new softmax reference");
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            float mx = half_max(rmax[qb]) * p.scale;      // rmax: taken beside the S^T MFMAs (stage_a)
-            // Lazy reference max: the rows of this block move to their current max only when some
-            // row's max has grown by more than kRescaleThr since the reference was taken (or has
-            // no reference yet).  In between, P = exp(s - m_ref) may exceed 1 (by at most
-            // e^kRescaleThr): harmless in fp32 sums and in bf16 P, whose relative precision does
-            // not depend on magnitude -- and O, l and L come out the same.
-            const bool grow = mx > m_run[qb] + kRescaleThr;        // also true from m_run = -inf
-            const bool any_grow = __any(grow);
-            const float m_new = any_grow ? fmaxf(m_run[qb], mx) : m_run[qb];
-            // O only needs scaling if some row already accumulated something at an older reference
-            need[qb] = any_grow && __any(m_run[qb] != -INFINITY && m_new != m_run[qb]);
-            // first visible key of a row: m_run = -inf -> alpha = 0 (its accumulators are 0 anyway)
-            alpha[qb] = m_new == -INFINITY ? 1.0f : __builtin_amdgcn_exp2f((m_run[qb] - m_new) * kLog2e);
-            m_run[qb] = m_new;
-            // a row that has seen no visible key yet keeps p = 0 (avoid inf - inf)
-            mb[qb] = m_new == -INFINITY ? 0.0f : m_new * kLog2e;
-            psum[qb] = 0.0f;
+            for (int qb = 0; qb < 2; ++qb) {
+                const float mx = half_max(rmax[qb]) * p.scale;
+                const bool grow = mx > m_run[qb] + kRescaleThr;        // also true from m_run = -inf
+                const bool any_grow = __any(grow);
+                const float m_new = any_grow ? fmaxf(m_run[qb], mx) : m_run[qb];
+                // O only needs scaling if some row already accumulated something at an older reference
+                need[qb] = any_grow && __any(m_run[qb] != -INFINITY && m_new != m_run[qb]);
+                // first visible key of a row: m_run = -inf -> alpha = 0 (its accumulators are 0 anyway)
+                alpha[qb] = m_new == -INFINITY ? 1.0f : __builtin_amdgcn_exp2f((m_run[qb] - m_new) * kLog2e);
+                m_run[qb] = m_new;
+                // a row that has seen no visible key yet keeps p = 0 (avoid inf - inf)
+                mb[qb] = m_new == -INFINITY ? 0.0f : m_new * kLog2e;
+                thr[qb] = (m_new + kRescaleThr) * inv_scale;
+                l_run[qb] *= alpha[qb];
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
 
+        uint32_t pw[2][8];       // packed P of half-tile u: word 4s + i = registers 8s + 2i, 8s + 2i + 1
         static_for<NG>([&](auto G) {
             constexpr int g = decltype(G)::value;
             constexpr int dt = g >> 1, sp = g & 1;
-            bf16x4 vn0 = va0, vn1 = va1;
-#ifdef FA2_ABL_NOTR
-            if constexpr (false) {
-#else
-            if constexpr (g + 1 < NG) {
-#endif
-                constexpr int dtn = (g + 1) >> 1;
-                constexpr int spo = ((g + 1) & 1) * 16 * ROWB;
-                lds_read_tr2_asm<VOFF + spo>(vn0, vn1, lbase + toff[dtn][0], lbase + toff[dtn][1]);
-                lds_tr_wait2<2>(va0, va1);
-            } else {
-                lds_tr_wait2<0>(va0, va1);
-            }
             bf16x8 vf;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { vf[e] = va0[e]; vf[4 + e] = va1[e]; }
-            // the S tiles of the current half-tile are threaded through the statement: the
-            // exponentials below stay between this group's MFMAs and the next group's
-            acc_mfma2<A_O + (0 * DT + dt) * 16, A_O + (1 * DT + dt) * 16>(vf, pprev[0][sp], pprev[1][sp], scur[0], scur[1],
-                                                                            psum[0], psum[1]);
-            va0 = vn0; va1 = vn1;
+            // the S tiles of the current half-tile and the running sums are threaded through the
+            // statement: the exponentials below stay between this group's MFMAs and the next group's
+            if constexpr (g + 1 < NG) {
+                constexpr int dtn = (g + 1) >> 1;
+                constexpr int spo = ((g + 1) & 1) * 16 * ROWB;
+                bf16x4 vn0, vn1;
+                pv_group_next<VOFF + spo, A_O + (0 * DT + dt) * 16, A_O + (1 * DT + dt) * 16>(
+                    vn0, vn1, lbase + toff[dtn][0], lbase + toff[dtn][1], vf, pprev[0][sp], pprev[1][sp], scur[0], scur[1],
+                    l_run[0], l_run[1]);
+                va0 = vn0; va1 = vn1;
+            } else {
+                pv_group_last<A_O + (0 * DT + dt) * 16, A_O + (1 * DT + dt) * 16>(vf, pprev[0][sp], pprev[1][sp], scur[0],
+                                                                                  scur[1], l_run[0], l_run[1]);
+            }
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-                for (int r = g * RPG; r < (g + 1) * RPG; ++r) {
-#ifdef FA2_ABL_NOEXP
-                    continue;
+                for (int r = g * RPG; r < (g + 1) * RPG; r += 2) {
+                    const float e0 = __builtin_amdgcn_exp2f(scur[qb][r] * c2 - mb[qb]);
+                    const float e1 = __builtin_amdgcn_exp2f(scur[qb][r + 1] * c2 - mb[qb]);
+                    pw[qb][r >> 1] = pack_bf16_pair(e0, e1);
+#if defined(FA2_SUM_DOT2)
+                    sum_bf16_pair(l_run[qb], pw[qb][r >> 1]);
+#elif defined(FA2_SUM_PK)
+                    l_run[qb] += f32x2{e0, e1};
+#else
+                    l_run[qb] += e0 + e1;
 #endif
-                    const float e = __builtin_amdgcn_exp2f(scur[qb][r] * c2 - mb[qb]);
-                    scur[qb][r] = e;
-                    psum[qb] += e;
                 }
-            keep_alive(vf);
         });
-        thread2f(scur[0], scur[1], psum[0], psum[1]);
+        thread2f(scur[0], scur[1], l_run[0], l_run[1]);
 
-        static_for<2>([&](auto QB) {
-            constexpr int qb = decltype(QB)::value;
-            l_run[qb] = l_run[qb] * alpha[qb] + psum[qb];
-            if (need[qb]) {     // everything accumulated so far (through half-tile u-1) is at the old max
-                mfma_acc_settle();
-                static_for<4 * DT>([&](auto R4) { acc_scale4<A_O + qb * DT * 16 + 4 * decltype(R4)::value>(alpha[qb]); });
+        if (need[0] || need[1]) {   // everything accumulated so far (through half-tile u-1) is at the old reference
+            mfma_acc_settle();
+            static_for<2>([&](auto QB) {
+                constexpr int qb = decltype(QB)::value;
+                if (need[qb])
+                    static_for<4 * DT>([&](auto R4) { acc_scale4<A_O + qb * DT * 16 + 4 * decltype(R4)::value>(alpha[qb]); });
+            });
+        }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                const u32x4 w = {pw[qb][4 * sp], pw[qb][4 * sp + 1], pw[qb][4 * sp + 2], pw[qb][4 * sp + 3]};
+                pprev[qb][sp] = __builtin_bit_cast(bf16x8, w);
             }
-            pprev[qb][0] = pack_acc(scur[qb], 0);
-            pprev[qb][1] = pack_acc(scur[qb], 1);
-        });
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -339,31 +360,60 @@ __global__ void __launch_bounds__(256, 1) fa2_fwd_bf16_kernel(FwdArgs p)
     //   step 1 (u = 2T)  : A on K[T] second half       ; X(u) ; B on V[T-1] second half (buffer B+2)
     //   barrier          : buffer B+2 is free, tile T+1 has landed -> DMA tile T+2 into B+2
     //   step 2 (u = 2T+1): A on K[T+1] first half (B+1) ; X(u) ; B on V[T] first half
+#ifdef FA2_DIAG_STAMPS
+    unsigned long long dg_a = 0, dg_xb = 0, dg_sync = 0, dg_t = 0, dg_loop = 0;
+#define FA2_STAMP(acc) { unsigned long long ts_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_) :: "memory"); acc += ts_ - dg_t; dg_t = ts_; }
+#else
+#define FA2_STAMP(acc)
+#endif
     auto tile = [&](auto B_, int T) {
         constexpr int B = decltype(B_)::value;
         constexpr int B1 = (B + 1) % kFwdBufs, B2 = (B + 2) % kFwdBufs;
         f32x16 snext[2];
         stage_a(std::integral_constant<int, B * TILEB + HALFB>{}, T * kFwdKV + 32, snext, true);
+        FA2_STAMP(dg_a)
         stage_xb(std::integral_constant<int, B2 * TILEB + HALFB>{});
         scur[0] = snext[0]; scur[1] = snext[1];
+        FA2_STAMP(dg_xb)
+#ifndef FA2_ABL_NOBAR
         __syncthreads();
+#endif
+#ifndef FA2_ABL_NODMA
         stage(T + 2, B2);
+#endif
+        FA2_STAMP(dg_sync)
         stage_a(std::integral_constant<int, B1 * TILEB>{}, (T + 1) * kFwdKV, snext, true);
+        FA2_STAMP(dg_a)
         stage_xb(std::integral_constant<int, B * TILEB>{});
         scur[0] = snext[0]; scur[1] = snext[1];
+        FA2_STAMP(dg_xb)
     };
 
+#ifdef FA2_DIAG_STAMPS
+    { unsigned long long ts_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_) :: "memory"); dg_t = ts_; dg_loop = ts_; }
+#endif
     for (int T = 0; T < niter; T += 3) {
         tile(std::integral_constant<int, 0>{}, T);
         tile(std::integral_constant<int, 1>{}, T + 1);
         tile(std::integral_constant<int, 2>{}, T + 2);
     }
+#ifdef FA2_DIAG_STAMPS
+    if (lane == 0) {   // diagnostic build only: cycle sums overwrite the head of L
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.L) + ((size_t)blockIdx.x * kFwdWaves + wave) * 4;
+        dbg[0] = dg_a; dbg[1] = dg_xb; dbg[2] = dg_sync; dbg[3] = dg_t - dg_loop;
+    }
+    return;
+#endif
 
     // ---- epilogue
     mfma_acc_settle();
     static_for<2>([&](auto QB) {
         constexpr int qb = decltype(QB)::value;
+#ifdef FA2_SUM_PK
+        const float l_tot = half_sum(l_run[qb][0] + l_run[qb][1]);
+#else
         const float l_tot = half_sum(l_run[qb]);
+#endif
         const size_t qoff = (size_t)head * Nq + qrow[qb];
         const bool fin = !STATE || p.finalize;
         const float inv = fin ? (l_tot > 0.0f ? 1.0f / l_tot : 0.0f) : 1.0f;
