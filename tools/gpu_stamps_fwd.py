@@ -10,9 +10,12 @@ torch.cuda.synchronize()
 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
 for _ in range(5): fa.flash_attention_2_forward(Q, K, V, None, O=O, L=L)
 e1.record(); torch.cuda.synchronize(); ms = e0.elapsed_time(e1) / 5
-st = L.view(-1).view(torch.int64)[: 2048 * 4 * 4].view(-1, 4).double().cpu()
-a, xb, sy, tot = [st[:, i].mean().item() for i in range(4)]
+nw = 2048 * 8
+st = L.view(-1).view(torch.int64)[: nw * 8].view(-1, 8).double().cpu()
+a, x, b, r, sy, tot, vm, bar = [st[:, i].mean().item() for i in range(8)]
 steps = 2 * 129
-print("kernel %.3f ms; per wave loop ticks %.0f (x8 waves/SIMD = %.0f -> %.1f MHz if ticks are clocks)" % (ms, tot, 8 * tot, 8 * tot / ms / 1e3))
-print("per step: A %.0f  XB %.0f  sync+dma(per tile) %.0f ; share A %.1f%% XB %.1f%% sync %.1f%%" % (
-    a / steps, xb / steps, sy / 129, 100 * a / tot, 100 * xb / tot, 100 * sy / tot))
+print("kernel %.3f ms; per wave loop ticks %.0f (8 blocks per CU in turn -> %.1f MHz if ticks are clocks)" % (ms, tot, 8 * tot / ms / 1e3))
+print("per half-tile step (16 MFMAs per wave): A %.0f  X %.0f  B %.0f  rotate %.0f  barrier+dma(per tile) %.0f" % (
+    a / steps, x / steps, b / steps, r / steps, sy / 129))
+print("per tile: vmcnt wait %.0f, barrier wait %.0f, dma issue %.0f" % (vm / 129, bar / 129, sy / 129))
+print("share: A %.1f%% X %.1f%% B %.1f%% rot %.1f%% sync %.1f%%" % tuple(100 * v / tot for v in (a, x, b, r, sy)))
