@@ -29,6 +29,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2516.6   # MI355X dense bf16 MFMA: 256 CU x 4096 flop/clk x 2.4 GHz
+# What the chip sustains when every SIMD issues nothing but v_mfma_f32_32x32x16_bf16 on random
+# operands (tools/probes/mfma_power.hip): the clock settles near 1.77 GHz.  Reported beside the
+# nominal peak; `frac` is always against the nominal one.
+SUSTAINED_MFMA_TFLOPS = 1840.0
+# HBM bytes per launch from the PMC passes in profiles/r1_c_pmc_summary.txt (FETCH_SIZE doubled as
+# MI355X_MICROARCH.md prescribes for gfx950, plus WRITE_SIZE; units of 1024 B).  Collected with
+# rocprofv3 in separate passes, not inside this script.
+PMC_TRAFFIC_BYTES = {
+    "fa2_fwd_bf16_kernel": (2 * 196840 + 133120) * 1024,
+    "fa2_bwd_dq_kernel": (2 * 264346 + 131072) * 1024,
+    "fa2_bwd_dkdv_kernel": (2 * 268472 + 270369) * 1024,
+}
 B, H, N, D = 4, 16, 8192, 128
 
 
@@ -149,7 +161,9 @@ def main():
     dom = max(k_flops, key=lambda k: k_ms[k])
     achieved = k_flops[dom] / (k_ms[dom] * 1e-3) / 1e12
     roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                "traffic": PMC_TRAFFIC_BYTES.get(dom), "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
+                "sustained_mfma_peak": SUSTAINED_MFMA_TFLOPS, "frac_of_sustained": round(achieved / SUSTAINED_MFMA_TFLOPS, 4),
                 "flops_per_launch": k_flops[dom], "ms_per_launch": round(k_ms[dom], 4),
                 "kernels_ms": {k: round(v, 4) for k, v in k_ms.items()},
                 "whole_path_frac": round(value / world / PEAK_BF16_TFLOPS, 4)}

@@ -324,6 +324,11 @@ __global__ void __launch_bounds__(64 * kFwdWaves, 1) fa2_fwd_bf16_kernel(FwdArgs
     constexpr int KS = D / 16;                // k-steps of QK^T
     constexpr int DT = D / 32;                // 32-column tiles of O
 
+#ifdef FA2_DIAG_BLOCKS
+    unsigned long long bk_t0, bk_t1 = 0, bk_t2 = 0;
+    unsigned bk_hw;
+    asm volatile("s_memrealtime %0\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)\n\ts_waitcnt lgkmcnt(0)" : "=s"(bk_t0), "=s"(bk_hw) :: "memory");
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -564,6 +569,9 @@ __global__ void __launch_bounds__(64 * kFwdWaves, 1) fa2_fwd_bf16_kernel(FwdArgs
 #ifdef FA2_DIAG_STAMPS
     { unsigned long long ts_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_) :: "memory"); dg_t = ts_; dg_loop = ts_; }
 #endif
+#ifdef FA2_DIAG_BLOCKS
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(bk_t1) :: "memory");
+#endif
     for (int T = 0; T < niter; T += 3) {
         tile(std::integral_constant<int, 0>{}, T);
         tile(std::integral_constant<int, 1>{}, T + 1);
@@ -577,6 +585,9 @@ __global__ void __launch_bounds__(64 * kFwdWaves, 1) fa2_fwd_bf16_kernel(FwdArgs
     return;
 #endif
 
+#ifdef FA2_DIAG_BLOCKS
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(bk_t2) :: "memory");
+#endif
     // ---- epilogue
     mfma_acc_settle();
     const float l_tot = half_sum(l_run);
@@ -600,7 +611,11 @@ __global__ void __launch_bounds__(64 * kFwdWaves, 1) fa2_fwd_bf16_kernel(FwdArgs
             }
         }
     });
+#ifdef FA2_DIAG_BLOCKS
+    if (false) {
+#else
     if (qrow < Nq && h == 0) {
+#endif
         if (fin) {
             p.L[qoff] = m_run + __builtin_logf(l_tot);
         } else {
@@ -608,6 +623,15 @@ __global__ void __launch_bounds__(64 * kFwdWaves, 1) fa2_fwd_bf16_kernel(FwdArgs
             p.M[qoff] = m_run;
         }
     }
+#ifdef FA2_DIAG_BLOCKS
+    __syncthreads();
+    if (tid == 0) {     // diagnostic build only: block timeline (100 MHz ticks) over the tail of L
+        unsigned long long bk_t3;
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(bk_t3) :: "memory");
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.L + (size_t)p.BH * Nq) - 8 * (size_t)(gridDim.x - blockIdx.x);
+        dbg[0] = bk_t0; dbg[1] = bk_t1; dbg[2] = bk_t2; dbg[3] = bk_t3; dbg[4] = bk_hw;
+    }
+#endif
 }
 
 template <int D, bool CAUSAL, bool STATE>
