@@ -526,6 +526,8 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dkdv_kernel(BwdArgs p)
 
         const int qb0 = t * TROWS + 32 * sh;
         // accumulators start from the row constants: S' = Q K^T - L/scale, dP' = dO V^T - D
+        // (the constants go into the first key block's tile only; the second chain takes them as its C
+        // operand: mfma2_vv_cinit)
         f32x16 sacc[2], dpacc[2];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -533,8 +535,8 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dkdv_kernel(BwdArgs p)
             const f32x4 b = *reinterpret_cast<const f32x4*>(rcs + 64 + 8 * g + 4 * h);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                sacc[0][4 * g + e] = a[e]; sacc[1][4 * g + e] = a[e];
-                dpacc[0][4 * g + e] = b[e]; dpacc[1][4 * g + e] = b[e];
+                sacc[0][4 * g + e] = a[e];
+                dpacc[0][4 * g + e] = b[e];
             }
         }
         // ---- stage A: S'[q][key] for both key blocks, Q row fragments read one k-step ahead
@@ -543,7 +545,8 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dkdv_kernel(BwdArgs p)
             constexpr int sidx = decltype(S)::value;
             bf16x8 qn = qa;
             if constexpr (sidx + 1 < KS) qn = lds_read_frag(Qt, roff[sidx + 1]);
-            mfma2_vv(sacc[0], sacc[1], qa, kf[0][sidx], kf[1][sidx]);
+            if constexpr (sidx == 0) mfma2_vv_cinit(sacc[0], sacc[1], qa, kf[0][sidx], kf[1][sidx]);
+            else mfma2_vv(sacc[0], sacc[1], qa, kf[0][sidx], kf[1][sidx]);
             qa = qn;
         });
         __builtin_amdgcn_sched_barrier(0);
@@ -563,7 +566,9 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dkdv_kernel(BwdArgs p)
                 v0n = lds_read_frag(Vw, roff[sidx + 1]);
                 v1n = lds_read_frag(Vw, roff[sidx + 1] + 32 * ROWB);
             }
-            mfma2_vv(dpacc[0], dpacc[1], ga, v0, v1, sacc[0], sacc[1]);     // S' tiles threaded through: see below
+            if constexpr (sidx == 0) mfma2_vv_cinit(dpacc[0], dpacc[1], ga, v0, v1);
+            else mfma2_vv(dpacc[0], dpacc[1], ga, v0, v1);
+            __builtin_amdgcn_sched_barrier(0);       // the exponentials stay between this step's MFMAs and the next's
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -603,18 +608,19 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dkdv_kernel(BwdArgs p)
         static_for<2 * DT>([&](auto G) {
             constexpr int g = decltype(G)::value;
             constexpr int dt = g >> 1, sp = g & 1;
-            bf16x4 tn0 = ta0, tn1 = ta1;
-            if constexpr (g + 1 < 2 * DT) {
-                constexpr int dtn = (g + 1) >> 1, spo = ((g + 1) & 1) * SPB;
-                lds_read_tr2_asm<GB + spo>(tn0, tn1, lbase + toff[dtn][0], lbase + toff[dtn][1]);
-            } else {                                    // first Q^T fragment of stage D
-                lds_read_tr2_asm<QB>(tn0, tn1, lbase + toff[0][0], lbase + toff[0][1]);
-            }
-            lds_tr_wait2<2>(ta0, ta1);
             bf16x8 gT;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { gT[e] = ta0[e]; gT[4 + e] = ta1[e]; }
-            mfma2_acc(dvacc[0][dt], dvacc[1][dt], gT, pf[0][sp], pf[1][sp], dpacc[0], dpacc[1]);
+            bf16x4 tn0, tn1;
+            if constexpr (g + 1 < 2 * DT) {
+                constexpr int dtn = (g + 1) >> 1, spo = ((g + 1) & 1) * SPB;
+                tr_mfma2_acc_next<GB + spo>(tn0, tn1, lbase + toff[dtn][0], lbase + toff[dtn][1], dvacc[0][dt], dvacc[1][dt], gT,
+                                            pf[0][sp], pf[1][sp]);
+            } else {                                    // first Q^T fragment of stage D
+                tr_mfma2_acc_next<QB>(tn0, tn1, lbase + toff[0][0], lbase + toff[0][1], dvacc[0][dt], dvacc[1][dt], gT, pf[0][sp],
+                                      pf[1][sp]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -629,23 +635,23 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dkdv_kernel(BwdArgs p)
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) dsf[kb][sp] = pack_acc(dpacc[kb], sp);
 
-        // ---- stage D: dK^T[dcol][key] += Q^T[dcol][q] dS[q][key]
+        // ---- stage D: dK^T[dcol][key] += Q^T[dcol][q] dS[q][key]  (the first group reads dS fragments the
+        // VALU packed a moment ago: padded)
         static_for<2 * DT>([&](auto G) {
             constexpr int g = decltype(G)::value;
             constexpr int dt = g >> 1, sp = g & 1;
-            bf16x4 tn0 = ta0, tn1 = ta1;
-            if constexpr (g + 1 < 2 * DT) {
-                constexpr int dtn = (g + 1) >> 1, spo = ((g + 1) & 1) * SPB;
-                lds_read_tr2_asm<QB + spo>(tn0, tn1, lbase + toff[dtn][0], lbase + toff[dtn][1]);
-                lds_tr_wait2<2>(ta0, ta1);
-            } else {
-                lds_tr_wait2<0>(ta0, ta1);
-            }
             bf16x8 qT;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { qT[e] = ta0[e]; qT[4 + e] = ta1[e]; }
-            mfma2_acc(dkacc[0][dt], dkacc[1][dt], qT, dsf[0][sp], dsf[1][sp]);
-            ta0 = tn0; ta1 = tn1;
+            if constexpr (g + 1 < 2 * DT) {
+                constexpr int dtn = (g + 1) >> 1, spo = ((g + 1) & 1) * SPB;
+                bf16x4 tn0, tn1;
+                tr_mfma2_acc_next<QB + spo, g == 0>(tn0, tn1, lbase + toff[dtn][0], lbase + toff[dtn][1], dkacc[0][dt], dkacc[1][dt],
+                                                    qT, dsf[0][sp], dsf[1][sp]);
+                ta0 = tn0; ta1 = tn1;
+            } else {
+                tr_mfma2_acc_last(dkacc[0][dt], dkacc[1][dt], qT, dsf[0][sp], dsf[1][sp]);
+            }
         });
     };
     auto tile = [&](auto BUF, int t) {

@@ -369,6 +369,42 @@ __device__ __forceinline__ uint32_t pack_bf16_pair(float lo, float hi)
     return __builtin_bit_cast(uint32_t, v);
 }
 
+// Two accumulations into hipcc-allocated AGPR tiles that share their A operand, fused with the two
+// transposed reads of the NEXT fragment (n0, n1) and the wait that leaves exactly those in flight,
+// in ONE statement and without a pad: a, b0, b1 must not have been written by the VALU within the
+// two instructions before it (PAD = true adds the two wait states when that cannot be guaranteed).
+template <int IMM, bool PAD = false>
+__device__ __forceinline__ void tr_mfma2_acc_next(bf16x4& n0, bf16x4& n1, uint32_t addr0, uint32_t addr1, f32x16& c0,
+                                                  f32x16& c1, bf16x8 a, bf16x8 b0, bf16x8 b1)
+{
+    if constexpr (PAD)
+        asm volatile("ds_read_b64_tr_b16 %0, %4 offset:%c6\n\tds_read_b64_tr_b16 %1, %5 offset:%c6\n\t"
+                     "s_waitcnt lgkmcnt(2)\n\ts_nop 1\n\t"
+                     "v_mfma_f32_32x32x16_bf16 %2, %7, %8, %2\n\tv_mfma_f32_32x32x16_bf16 %3, %7, %9, %3"
+                     : "=&v"(n0), "=&v"(n1), "+a"(c0), "+a"(c1)
+                     : "v"(addr0), "v"(addr1), "i"(IMM), "v"(a), "v"(b0), "v"(b1));
+    else
+        asm volatile("ds_read_b64_tr_b16 %0, %4 offset:%c6\n\tds_read_b64_tr_b16 %1, %5 offset:%c6\n\t"
+                     "s_waitcnt lgkmcnt(2)\n\t"
+                     "v_mfma_f32_32x32x16_bf16 %2, %7, %8, %2\n\tv_mfma_f32_32x32x16_bf16 %3, %7, %9, %3"
+                     : "=&v"(n0), "=&v"(n1), "+a"(c0), "+a"(c1)
+                     : "v"(addr0), "v"(addr1), "i"(IMM), "v"(a), "v"(b0), "v"(b1));
+}
+// The last pair of a run: nothing further to read, everything outstanding must have landed.
+__device__ __forceinline__ void tr_mfma2_acc_last(f32x16& c0, f32x16& c1, bf16x8 a, bf16x8 b0, bf16x8 b1)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                 "v_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %2, %4, %1"
+                 : "+a"(c0), "+a"(c1) : "v"(a), "v"(b0), "v"(b1));
+}
+// First k-step of two chains that start from the SAME constant tile: c0 holds the constants on entry,
+// c1 is written from them (C operand = c0) before c0 is accumulated in place -- no copy of the tile.
+__device__ __forceinline__ void mfma2_vv_cinit(f32x16& c0, f32x16& c1, bf16x8 a, bf16x8 b0, bf16x8 b1)
+{
+    asm volatile("v_mfma_f32_32x32x16_bf16 %1, %2, %4, %0\n\tv_mfma_f32_32x32x16_bf16 %0, %2, %3, %0"
+                 : "+v"(c0), "=&v"(c1) : "v"(a), "v"(b0), "v"(b1));
+}
+
 // Both halves of one transposed fragment in one statement.
 template <int IMM>
 __device__ __forceinline__ void lds_read_tr2_asm(bf16x4& r0, bf16x4& r1, uint32_t addr0, uint32_t addr1)
