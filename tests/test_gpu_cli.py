@@ -61,6 +61,8 @@ def test_02_backward_shape_args():
 def test_03_ring_reference_case_and_verify():
     rc, out = run("01_rccl_verify")
     assert rc == 0 and "Ring verify PASSED" in out, out
+    rc, out = run("02_overlap", 1, 4, 1024, 128, 2)
+    assert rc == 0 and "Overlap test completed!" in out and "Received block starting with 1 (expected 1 from rank 0)" in out, out
     rc, out = run("04_ring_attention")
     assert rc == 0, out
     assert "All outputs match within tolerance (rtol=5.0e-03, atol=1.0)" in out and "Test PASSED!" in out
