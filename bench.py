@@ -186,6 +186,27 @@ def main():
         except Exception as e:  # the baseline is a reported side figure, never fatal
             out["cpu_baseline"] = {"error": repr(e)}
 
+    # ---- side figures SURVEY 8d asks for beside the headline: forward only at BASELINE configs[1] (bf16)
+    # and the fp8 causal forward of configs[4] (B and H unspecified there: B=1, H=16)
+    if rank == 0:
+        try:
+            extra = {}
+            def fwd_only(Bx, Hx, Nx, dx, dt, causal):
+                mkx = lambda: (torch.rand(Bx, Hx, Nx, dx, device=dev) - 0.5).to(dt)
+                q, k, v = mkx(), mkx(), mkx()
+                o = torch.empty(Bx, Hx, Nx, dx, dtype=torch.bfloat16, device=dev)
+                l = torch.empty(Bx, Hx, Nx, dtype=torch.float32, device=dev)
+                f = lambda: fa.flash_attention_2_forward(q, k, v, None, causal=causal, O=o, L=l)
+                f(); f()
+                ms = timed(f, 5, torch)
+                fl = 4.0 * Bx * Hx * Nx * Nx * dx * (0.5 if causal else 1.0)
+                return {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1)}
+            extra["fwd_bf16_cfg2_(4,16,4096,64)"] = fwd_only(4, 16, 4096, 64, torch.bfloat16, False)
+            extra["fwd_fp8_e4m3_causal_cfg5_(1,16,32768,128)"] = fwd_only(1, 16, 32768, 128, torch.float8_e4m3fn, True)
+            out["side_figures"] = extra
+        except Exception as e:
+            out["side_figures"] = {"error": repr(e)}
+
     if not args.no_ring:
         try:
             from cuda_flashattention_amd import ring

@@ -17,6 +17,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "fa2_mi355x.h")
 FA2_OK = 0
 FA2_DTYPE_BF16 = 0
 FA2_DTYPE_F32 = 1
+FA2_DTYPE_FP8_E4M3 = 2
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -30,6 +31,8 @@ SIGNATURES = {
     "flash_attention_2_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f]),
     "flash_attention_2_backward": (_i, [_vp] * 9 + [_i, _i, _f]),
     "fa2_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp]),
+    "fa2_forward_fp8_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "fa2_forward_fp8": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
     "fa2_backward_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "fa2_backward": (_i, [_vp] * 9 + [_i, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp]),
     "fa2_backward_phases": (_i, [_vp] * 9 + [_i, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp, _i]),

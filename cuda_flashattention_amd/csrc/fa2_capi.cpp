@@ -24,6 +24,7 @@ inline int check_dim(int d, int dtype)
 {
     if (dtype == FA2_DTYPE_BF16) return (d == 64 || d == 128) ? FA2_OK : FA2_ERR_UNSUPPORTED_HEAD_DIM;
     if (dtype == FA2_DTYPE_F32) return (d >= 1 && d <= 128) ? FA2_OK : FA2_ERR_UNSUPPORTED_HEAD_DIM;
+    if (dtype == FA2_DTYPE_FP8_E4M3) return d == 128 ? FA2_OK : FA2_ERR_UNSUPPORTED_HEAD_DIM;
     return FA2_ERR_UNSUPPORTED_DTYPE;
 }
 
@@ -97,11 +98,44 @@ int fa2_forward(const void* Q, const void* K, const void* V, void* O, float* L,
         a.causal = causal ? 1 : 0; a.causal_shift = 0; a.resume = 0; a.finalize = 1;
         return hip_status(fa2::launch_fwd_bf16(a, (hipStream_t)stream));
     }
+    if (dtype == FA2_DTYPE_FP8_E4M3) {      // workspace from the stream-ordered allocator
+        const size_t need = fa2_forward_fp8_workspace_bytes(B, H, seq_len, head_dim);
+        void* ws = nullptr;
+        hipError_t e = hipMallocAsync(&ws, need, (hipStream_t)stream);
+        if (e != hipSuccess) return hip_status(e);
+        st = fa2_forward_fp8(Q, K, V, O, L, B, H, seq_len, head_dim, softmax_scale, causal, ws, need, stream);
+        e = hipFreeAsync(ws, (hipStream_t)stream);
+        return st ? st : hip_status(e);
+    }
     fa2::F32Args a{};
     a.Q = (const float*)Q; a.K = (const float*)K; a.V = (const float*)V; a.O = (float*)O; a.L = L;
     a.BH = B * H; a.N = seq_len; a.d = head_dim; a.scale = softmax_scale; a.causal = causal ? 1 : 0;
     a.Nk = seq_len; a.M = nullptr; a.resume = 0; a.finalize = 1;
     return hip_status(fa2::launch_fwd_f32(a, (hipStream_t)stream));
+}
+
+size_t fa2_forward_fp8_workspace_bytes(int B, int H, int seq_len, int head_dim)
+{
+    if (B <= 0 || H <= 0 || seq_len <= 0 || head_dim != 128) return 0;
+    const size_t npad = ((size_t)seq_len + 63) / 64 * 64;
+    return (size_t)B * H * head_dim * npad;
+}
+
+int fa2_forward_fp8(const void* Q, const void* K, const void* V, void* O, float* L,
+                    int B, int H, int seq_len, int head_dim, float softmax_scale, int causal,
+                    void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!Q || !K || !V || !O || !L) return FA2_ERR_NULL_POINTER;
+    int st = check_common(B, H, seq_len, head_dim, softmax_scale);
+    if (st) return st;
+    st = check_dim(head_dim, FA2_DTYPE_FP8_E4M3);
+    if (st) return st;
+    if (!workspace || workspace_bytes < fa2_forward_fp8_workspace_bytes(B, H, seq_len, head_dim)) return FA2_ERR_WORKSPACE;
+    fa2::FwdFp8Args a{};
+    a.Q = Q; a.K = K; a.V = V; a.Vt = workspace; a.O = O; a.L = L;
+    a.BH = B * H; a.N = seq_len; a.Npad = (seq_len + 63) / 64 * 64; a.d = head_dim;
+    a.scale = softmax_scale; a.causal = causal ? 1 : 0;
+    return hip_status(fa2::launch_fwd_fp8(a, (hipStream_t)stream));
 }
 
 size_t fa2_backward_workspace_bytes(int B, int H, int seq_len, int head_dim, int dtype)
@@ -130,6 +164,7 @@ int fa2_backward_phases(const void* Q, const void* K, const void* V, const void*
     if (!Q || !K || !V || !O || !L || !dO || !dQ || !dK || !dV) return FA2_ERR_NULL_POINTER;
     int st = check_common(B, H, seq_len, head_dim, softmax_scale);
     if (st) return st;
+    if (dtype == FA2_DTYPE_FP8_E4M3) return FA2_ERR_UNSUPPORTED_DTYPE;      // fp8 is forward only
     st = check_dim(head_dim, dtype);
     if (st) return st;
     if (!workspace || workspace_bytes < fa2_backward_workspace_bytes(B, H, seq_len, head_dim, dtype))
@@ -159,6 +194,7 @@ int fa2_forward_step(const void* Q, const void* K, const void* V,
     int st = check_common(B, H, q_len, head_dim, softmax_scale);
     if (st) return st;
     if (kv_len <= 0) return FA2_ERR_INVALID_SHAPE;
+    if (dtype == FA2_DTYPE_FP8_E4M3) return FA2_ERR_UNSUPPORTED_DTYPE;      // no resumable fp8 step
     st = check_dim(head_dim, dtype);
     if (st) return st;
     if (dtype == FA2_DTYPE_F32) {

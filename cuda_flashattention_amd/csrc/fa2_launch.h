@@ -28,6 +28,19 @@ struct FwdArgs {
 
 hipError_t launch_fwd_bf16(const FwdArgs& a, hipStream_t stream);
 
+// fp8 (OCP e4m3) forward, d = 128: Q, K, V fp8 [BH][N][128]; O bf16; Vt: [BH][128][Npad] fp8 scratch the
+// launcher fills with V transposed (Npad = N rounded up to 64).
+struct FwdFp8Args {
+    const void* Q; const void* K; const void* V;
+    void* Vt;
+    void* O;
+    float* L;
+    int BH, N, Npad, d;
+    float scale;
+    int causal;
+};
+hipError_t launch_fwd_fp8(const FwdFp8Args& a, hipStream_t stream);
+
 struct BwdArgs {
     const void* Q; const void* K; const void* V; const void* O; const void* dO;  // bf16
     const float* L;   // [BH][N] natural-log LSE from the forward

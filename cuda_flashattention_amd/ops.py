@@ -11,7 +11,7 @@ import math
 import torch
 
 from . import _capi
-from ._capi import FA2_DTYPE_BF16, FA2_DTYPE_F32, check
+from ._capi import FA2_DTYPE_BF16, FA2_DTYPE_F32, FA2_DTYPE_FP8_E4M3, check
 
 
 def _dtype_code(t):
@@ -19,7 +19,9 @@ def _dtype_code(t):
         return FA2_DTYPE_BF16
     if t.dtype == torch.float32:
         return FA2_DTYPE_F32
-    raise TypeError(f"unsupported dtype {t.dtype}: bf16 or fp32 expected")
+    if t.dtype == torch.float8_e4m3fn:
+        return FA2_DTYPE_FP8_E4M3
+    raise TypeError(f"unsupported dtype {t.dtype}: bf16, fp32 or float8_e4m3fn (forward only) expected")
 
 
 def _stream_ptr(stream=None):
@@ -48,8 +50,8 @@ def flash_attention_2_forward(Q, K, V, softmax_scale=None, causal=False, O=None,
         if _bhnd(t, n) != (B, H, N, d) or t.dtype != Q.dtype:
             raise ValueError(f"{n} must match Q in shape and dtype")
     scale = float(softmax_scale) if softmax_scale is not None else 1.0 / math.sqrt(d)
-    if O is None:
-        O = torch.empty_like(Q)
+    if O is None:     # fp8 inputs (OCP e4m3, d = 128, BASELINE configs[4]) produce a bf16 O
+        O = torch.empty(Q.shape, dtype=torch.bfloat16, device=Q.device) if Q.dtype == torch.float8_e4m3fn else torch.empty_like(Q)
     if L is None:
         L = torch.empty(Q.shape[:-1], dtype=torch.float32, device=Q.device)
     st = _capi.lib().fa2_forward(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), L.data_ptr(),

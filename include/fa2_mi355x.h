@@ -47,6 +47,7 @@ extern "C" {
 /* ---- element types of Q/K/V/O/dO/dQ/dK/dV -------------------------------------------- */
 #define FA2_DTYPE_BF16 0   /* primary: bf16 in, fp32 accumulate on v_mfma_f32_32x32x16_bf16 */
 #define FA2_DTYPE_F32  1   /* the reference's type: exact f32 MFMA (v_mfma_f32_32x32x2_f32)  */
+#define FA2_DTYPE_FP8_E4M3 2 /* forward only: OCP e4m3 Q/K/V on v_mfma_f32_32x32x64_f8f6f4, O in bf16, d = 128 */
 
 const char* fa2_version(void);
 const char* fa2_status_string(int status);
@@ -79,6 +80,16 @@ int flash_attention_2_backward(const float* Q, const float* K, const float* V,
 int fa2_forward(const void* Q, const void* K, const void* V, void* O, float* L,
                 int B, int H, int seq_len, int head_dim, float softmax_scale,
                 int dtype, int causal, void* stream);
+
+/* fp8 (OCP e4m3) forward, BASELINE configs[4]: Q, K, V are e4m3 [B][H][N][128], O is bf16, L fp32.  The
+ * kernel reads V through a transposed copy ([B][H][128][N rounded up to 64], e4m3) that this call writes
+ * into `workspace` first (fa2_forward_fp8_workspace_bytes).  fa2_forward(..., FA2_DTYPE_FP8_E4M3, ...) is
+ * the same call with the workspace taken from the stream-ordered allocator.  No counterpart in the
+ * reference (fp32 end to end): parity is against the oracle fed the e4m3-rounded inputs. */
+size_t fa2_forward_fp8_workspace_bytes(int B, int H, int seq_len, int head_dim);
+int fa2_forward_fp8(const void* Q, const void* K, const void* V, void* O, float* L,
+                    int B, int H, int seq_len, int head_dim, float softmax_scale, int causal,
+                    void* workspace, size_t workspace_bytes, void* stream);
 
 /* Bytes of scratch fa2_backward needs for this problem (D vector, fp32 staging). */
 size_t fa2_backward_workspace_bytes(int B, int H, int seq_len, int head_dim, int dtype);

@@ -1,0 +1,119 @@
+"""GPU: fp8 (OCP e4m3) forward -- BASELINE configs[4] -- through the C ABI against the oracle.
+
+fp8 has no counterpart in the reference (fp32 end to end): as SURVEY 8c prescribes, the inputs are
+rounded to e4m3 FIRST and the rounded values (up-cast to fp32) go to the fp64-accumulating oracle.
+Tolerance: rel-L2(O) <= 5e-2 -- P is carried in e4m3 for the second product (measured
+2.2e-2); L comes from unrounded fp32 sums, so it keeps the bf16 path's gate |dL| <= 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+FP8_REL = 5e-2
+
+
+def _fa():
+    import cuda_flashattention_amd as fa
+    return fa
+
+
+def _oracle():
+    import oracle
+    return oracle
+
+
+def rel(a, b):
+    return float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def make(B, H, N, d, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return ((torch.rand(B, H, N, d, generator=g) - 0.5) * scale).to(torch.float8_e4m3fn)
+
+
+def f32(t):
+    return t.float().cpu().numpy()
+
+
+@pytest.mark.parametrize("B,H,N,causal", [
+    (1, 1, 64, False),          # exactly one tile
+    (1, 1, 1, False),           # a single row
+    (1, 2, 320, False),
+    (1, 3, 333, False),         # ragged N, head count not a multiple of 8
+    (2, 8, 1024, False),
+    (1, 2, 256, True),
+    (1, 3, 777, True),
+    (1, 8, 2048, True),
+])
+def test_fwd_fp8_vs_oracle(B, H, N, causal):
+    fa, oracle = _fa(), _oracle()
+    d = 128
+    Q, K, V = make(B, H, N, d, 1), make(B, H, N, d, 2), make(B, H, N, d, 3)
+    s = 1.0 / d ** 0.5
+    O, L = fa.flash_attention_2_forward(Q.cuda(), K.cuda(), V.cuda(), s, causal=causal)
+    torch.cuda.synchronize()
+    assert O.dtype == torch.bfloat16
+    Or, Lr = oracle.attention_forward(f32(Q), f32(K), f32(V), s, causal=causal)
+    assert np.isfinite(f32(O)).all()
+    assert rel(f32(O), Or) <= FP8_REL
+    assert np.abs(f32(O) - Or).max() <= 2e-2
+    assert np.abs(L.cpu().numpy() - Lr).max() <= 1e-4
+
+
+def test_fwd_fp8_rescale_branch_forced():
+    """The lazy softmax reference must move when a late key dominates (P is kept below the e4m3 maximum)."""
+    fa, oracle = _fa(), _oracle()
+    B, H, N, d = 1, 2, 1024, 128
+    Q, K, V = make(B, H, N, d, 11), make(B, H, N, d, 12), make(B, H, N, d, 13)
+    Kf = K.float()
+    Kf[0, 0, 700] = Q.float()[0, 0].mean(0) * 40.0
+    Kf[0, 1, 64 * 9 + 5] = Q.float()[0, 1, 17] * 30.0
+    K = Kf.to(torch.float8_e4m3fn)
+    s = 1.0 / d ** 0.5
+    O, L = fa.flash_attention_2_forward(Q.cuda(), K.cuda(), V.cuda(), s)
+    torch.cuda.synchronize()
+    Or, Lr = oracle.attention_forward(f32(Q), f32(K), f32(V), s)
+    assert np.isfinite(f32(O)).all()
+    assert rel(f32(O), Or) <= FP8_REL
+    assert np.abs(L.cpu().numpy() - Lr).max() <= 1e-3
+
+
+def test_fwd_fp8_explicit_workspace_and_properties():
+    """fa2_forward_fp8 with a caller workspace equals fa2_forward(dtype = fp8); at the BASELINE configs[4]
+    row length rows of O are convex combinations of V rows (size-independent property)."""
+    fa = _fa()
+    lib = fa._capi.lib()
+    B, H, N, d = 1, 2, 4096, 128
+    Q, K, V = (make(B, H, N, d, s).cuda() for s in (5, 6, 7))
+    O1, L1 = fa.flash_attention_2_forward(Q, K, V, None, causal=True)
+    need = lib.fa2_forward_fp8_workspace_bytes(B, H, N, d)
+    assert need == B * H * d * N
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    O2 = torch.empty_like(O1)
+    L2 = torch.empty_like(L1)
+    st = lib.fa2_forward_fp8(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O2.data_ptr(), L2.data_ptr(), B, H, N, d,
+                             1.0 / d ** 0.5, 1, ws.data_ptr(), need, torch.cuda.current_stream().cuda_stream)
+    assert st == 0
+    torch.cuda.synchronize()
+    assert torch.equal(O1, O2) and torch.equal(L1, L2)
+    vmax = V.float().abs().amax().item()
+    assert O1.float().abs().amax().item() <= vmax * 1.01
+    # too small a workspace is a status code
+    st = lib.fa2_forward_fp8(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O2.data_ptr(), L2.data_ptr(), B, H, N, d,
+                             1.0 / d ** 0.5, 1, ws.data_ptr(), need - 1, torch.cuda.current_stream().cuda_stream)
+    assert st == -5
+
+
+def test_fp8_unsupported_combinations_are_status_codes():
+    fa = _fa()
+    Q = torch.zeros(1, 1, 64, 64, device="cuda").to(torch.float8_e4m3fn)       # d = 64: not built for fp8
+    with pytest.raises(fa._capi.FA2Error) as e:
+        fa.flash_attention_2_forward(Q, Q, Q)
+    assert e.value.status == -3
+    Q = torch.zeros(1, 1, 64, 128, device="cuda").to(torch.float8_e4m3fn)
+    O = torch.zeros(1, 1, 64, 128, dtype=torch.bfloat16, device="cuda")
+    L = torch.zeros(1, 1, 64, device="cuda")
+    with pytest.raises(fa._capi.FA2Error) as e:                                  # fp8 is forward only
+        fa.flash_attention_2_backward(Q, Q, Q, O, L, O)
+    assert e.value.status == -4
