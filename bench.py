@@ -102,7 +102,11 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+        backend = os.environ.get("FA2_BENCH_BACKEND", "nccl")      # "gloo": rehearsal of the N > 1 path on one GPU
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+        else:
+            dist.init_process_group(backend=backend)
 
     def barrier():
         if dist is not None:
