@@ -208,13 +208,43 @@ int fa2_forward_step(const void* Q, const void* K, const void* V,
         a.M = M; a.resume = first ? 0 : 1; a.finalize = last ? 1 : 0;
         return hip_status(fa2::launch_fwd_f32(a, (hipStream_t)stream));
     }
+    return fa2_forward_step_strided(Q, K, V, O, L, Oacc, M, B, H, q_len, kv_len, head_dim, softmax_scale, dtype, first,
+                                    last, 0, 0, 0, 0, stream);
+}
+
+int fa2_forward_step_strided(const void* Q, const void* K, const void* V,
+                             void* O, float* L, float* Oacc, float* M,
+                             int B, int H, int q_len, int kv_len, int head_dim, float softmax_scale,
+                             int dtype, int first, int last, int q_head_stride, int kv_head_stride,
+                             int causal, int causal_shift, void* stream)
+{
+    if (!Q || !K || !V || !L) return FA2_ERR_NULL_POINTER;
+    int st = check_common(B, H, q_len, head_dim, softmax_scale);
+    if (st) return st;
+    if (kv_len <= 0) return FA2_ERR_INVALID_SHAPE;
+    if (dtype != FA2_DTYPE_BF16) return FA2_ERR_UNSUPPORTED_DTYPE;
+    st = check_dim(head_dim, dtype);
+    if (st) return st;
+    if ((q_head_stride && q_head_stride < q_len) || (kv_head_stride && kv_head_stride < kv_len)) return FA2_ERR_INVALID_SHAPE;
     if (last && !O) return FA2_ERR_NULL_POINTER;
     if ((!first || !last) && (!Oacc || !M)) return FA2_ERR_NULL_POINTER;
     fa2::FwdArgs a{};
     a.Q = Q; a.K = K; a.V = V; a.O = O; a.L = L; a.Oacc = Oacc; a.M = M;
     a.BH = B * H; a.Nq = q_len; a.Nk = kv_len; a.d = head_dim; a.scale = softmax_scale;
-    a.causal = 0; a.causal_shift = 0; a.resume = first ? 0 : 1; a.finalize = last ? 1 : 0;
+    a.causal = causal ? 1 : 0; a.causal_shift = causal ? causal_shift : 0;
+    a.resume = first ? 0 : 1; a.finalize = last ? 1 : 0;
+    a.q_hs = q_head_stride; a.k_hs = kv_head_stride;
     return hip_status(fa2::launch_fwd_bf16(a, (hipStream_t)stream));
+}
+
+int fa2_forward_state_finalize(void* O, float* L, const float* Oacc, const float* M,
+                               size_t rows, int head_dim, int dtype, void* stream)
+{
+    if (!O || !L || !Oacc || !M) return FA2_ERR_NULL_POINTER;
+    if (dtype != FA2_DTYPE_BF16) return FA2_ERR_UNSUPPORTED_DTYPE;
+    int st = check_dim(head_dim, dtype);
+    if (st) return st;
+    return hip_status(fa2::launch_finalize_state(Oacc, M, L, O, rows, head_dim, (hipStream_t)stream));
 }
 
 int flash_attention_2_forward(const float* Q, const float* K, const float* V,

@@ -341,9 +341,10 @@ __global__ void __launch_bounds__(64 * kFwdWaves, 1) fa2_fwd_bf16_kernel(FwdArgs
     if (CAUSAL) rb = nrb - 1 - rb;            // heaviest row-blocks first
 
     const int Nq = p.Nq, Nk = p.Nk;
-    const char* Qh = (const char*)p.Q + (size_t)head * Nq * ROWB;
-    const char* Kh = (const char*)p.K + (size_t)head * Nk * ROWB;
-    const char* Vh = (const char*)p.V + (size_t)head * Nk * ROWB;
+    const size_t qhs = p.q_hs ? p.q_hs : Nq, khs = p.k_hs ? p.k_hs : Nk;     // rows between heads
+    const char* Qh = (const char*)p.Q + (size_t)head * qhs * ROWB;
+    const char* Kh = (const char*)p.K + (size_t)head * khs * ROWB;
+    const char* Vh = (const char*)p.V + (size_t)head * khs * ROWB;
 
     const int q0 = rb * kFwdRows + wave * 32;          // first query row of this wave
     const int qrow = q0 + qi;
@@ -374,7 +375,7 @@ __global__ void __launch_bounds__(64 * kFwdWaves, 1) fa2_fwd_bf16_kernel(FwdArgs
     const float inv_scale = 1.0f / p.scale;
     float m_run, l_run, mb, thr;
     if (STATE && p.resume) {
-        const float* Oa = p.Oacc + ((size_t)head * Nq + qld) * D;
+        const float* Oa = p.Oacc + ((size_t)head * qhs + qld) * D;
         static_for<4 * DT>([&](auto G) {
             constexpr int dt = decltype(G)::value / 4, g = decltype(G)::value % 4;
             const f32x4 v = *reinterpret_cast<const f32x4*>(Oa + 32 * dt + 8 * g + 4 * h);
@@ -383,8 +384,8 @@ __global__ void __launch_bounds__(64 * kFwdWaves, 1) fa2_fwd_bf16_kernel(FwdArgs
                 a128_write<A_O + dt * 16 + 4 * g + e>(v[e]);
             });
         });
-        m_run = p.M[(size_t)head * Nq + qld];
-        l_run = h == 0 ? p.L[(size_t)head * Nq + qld] : 0.0f;
+        m_run = p.M[(size_t)head * qhs + qld];
+        l_run = h == 0 ? p.L[(size_t)head * qhs + qld] : 0.0f;
         mb = m_run == -INFINITY ? 0.0f : m_run * kLog2e;
         thr = (m_run + kRescaleThr) * inv_scale;
     } else {
@@ -591,7 +592,7 @@ __global__ void __launch_bounds__(64 * kFwdWaves, 1) fa2_fwd_bf16_kernel(FwdArgs
     // ---- epilogue
     mfma_acc_settle();
     const float l_tot = half_sum(l_run);
-    const size_t qoff = (size_t)head * Nq + qrow;
+    const size_t qoff = (size_t)head * qhs + qrow;
     const bool fin = !STATE || p.finalize;
     const float inv = fin ? (l_tot > 0.0f ? 1.0f / l_tot : 0.0f) : 1.0f;
     static_for<4 * DT>([&](auto G) {

@@ -24,9 +24,13 @@ struct FwdArgs {
     int causal_shift; // global key index of the shard's first key minus that of the first query
     int resume;       // 1: start from (Oacc, L, M); 0: start from (0, 0, -inf)
     int finalize;     // 1: write O = acc / l and L = m + ln l; 0: store state
+    int q_hs, k_hs;   // rows between consecutive heads of Q/O/Oacc/L/M and of K/V (0: Nq, Nk -- dense slabs).
+                      // Larger strides address a row range of every head (the zig-zag chunks of the causal ring).
 };
 
 hipError_t launch_fwd_bf16(const FwdArgs& a, hipStream_t stream);
+// Ring epilogue: O = bf16(Oacc / l), L = m + ln l for `rows` consecutive rows (l arrives in L).
+hipError_t launch_finalize_state(const float* Oacc, const float* M, float* L, void* O, size_t rows, int d, hipStream_t stream);
 
 // fp8 (OCP e4m3) forward, d = 128: Q, K, V fp8 [BH][N][128]; O bf16; Vt: [BH][128][Npad] fp8 scratch the
 // launcher fills with V transposed (Npad = N rounded up to 64).

@@ -80,4 +80,35 @@ hipError_t launch_bf16_to_f32(const void* src, float* dst, size_t n, hipStream_t
     return hipGetLastError();
 }
 
+// Ring epilogue for the bf16 state layout (fa2_fwd_bf16.hip, STATE kernels): the un-normalised accumulator,
+// the running sum (in L) and the reference maximum become O = acc / l (bf16) and L = m + ln l -- what the
+// last step's finalize switch does, as a pass of its own for schedules in which the last step does not
+// touch every row (causal zig-zag ring).  One thread per 8 columns.
+__global__ void __launch_bounds__(256) finalize_state_kernel(const float* Oacc, const float* M, float* L, __bf16* O,
+                                                               size_t rows, int d)
+{
+    const int cpr = d / 8;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * cpr) return;
+    const size_t row = i / cpr;
+    const int c = (int)(i % cpr);
+    const float l = L[row];
+    const float inv = l > 0.0f ? 1.0f / l : 0.0f;
+    const float* a = Oacc + row * d + 8 * c;
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (__bf16)(a[e] * inv);
+    *reinterpret_cast<bf16x8*>(O + row * d + 8 * c) = o;
+    __syncthreads();          // every thread of a row has read l before one of them replaces it
+    if (c == 0) L[row] = M[row] + __builtin_logf(l);
+}
+
+hipError_t launch_finalize_state(const float* Oacc, const float* M, float* L, void* O, size_t rows, int d, hipStream_t stream)
+{
+    if (rows == 0) return hipSuccess;
+    const size_t n = rows * (size_t)(d / 8);
+    hipLaunchKernelGGL(finalize_state_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, Oacc, M, L, (__bf16*)O, rows, d);
+    return hipGetLastError();
+}
+
 }  // namespace fa2

@@ -171,17 +171,28 @@ int fa2_ring_exchange_kv(fa2_ring_ctx* c, const void* send_k, void* recv_k,
     return nccl_status(r);
 }
 
-int fa2_ring_attention_forward(fa2_ring_ctx* c,
-                               const void* Q_local, const void* K_local, const void* V_local,
-                               void* O_local, float* L_local,
-                               int B, int H, int total_seq_len, int local_seq_len, int head_dim,
-                               float softmax_scale, int dtype, int schedule,
-                               void* workspace, size_t workspace_bytes, void* stream_)
+}  // extern "C"
+
+// Shared driver of the plain and the causal (zig-zag) ring.  Causal layout: the sequence is cut into 2 P
+// chunks of c = local / 2 rows; rank r holds chunk r in its local rows [0, c) and chunk 2 P - 1 - r in rows
+// [c, 2 c).  With the shard of owner o resident: o == r is plain causal attention over the local rows (chunk
+// r precedes chunk 2 P - 1 - r); o < r means only the owner's FIRST chunk is visible, to every local
+// row, unmasked; o > r means BOTH its chunks are visible, unmasked, to the local rows of the second chunk
+// only.  Every step after the first therefore costs half a dense block on every rank -- the point of the
+// zig-zag order.  The last step need not touch every row, so results are produced by a finalize pass.
+static int ring_forward_impl(fa2_ring_ctx* c,
+                             const void* Q_local, const void* K_local, const void* V_local,
+                             void* O_local, float* L_local,
+                             int B, int H, int total_seq_len, int local_seq_len, int head_dim,
+                             float softmax_scale, int dtype, int schedule, int causal,
+                             void* workspace, size_t workspace_bytes, void* stream_)
 {
     if (!c || !Q_local || !K_local || !V_local || !O_local || !L_local) return FA2_ERR_NULL_POINTER;
     if (B <= 0 || H <= 0 || local_seq_len <= 0 || head_dim <= 0) return FA2_ERR_INVALID_SHAPE;
     const int P = c->nranks;
     if ((long long)local_seq_len * P != (long long)total_seq_len) return FA2_ERR_INVALID_SHAPE;  // 04_ring_attention.cu:55-63
+    if (causal && dtype != FA2_DTYPE_BF16) return FA2_ERR_UNSUPPORTED_DTYPE;
+    if (causal && (local_seq_len & 1)) return FA2_ERR_INVALID_SHAPE;
     if (dtype != FA2_DTYPE_BF16 && dtype != FA2_DTYPE_F32) return FA2_ERR_UNSUPPORTED_DTYPE;
     if (schedule != FA2_RING_RELAY && schedule != FA2_RING_MESH) return FA2_ERR_UNSUPPORTED;
     const Plan pl = make_plan(B, H, local_seq_len, head_dim, dtype, P, schedule);
@@ -196,13 +207,31 @@ int fa2_ring_attention_forward(fa2_ring_ctx* c,
     const size_t bytes = (size_t)B * H * local_seq_len * head_dim * elem_size(dtype);
     const int rank = c->rank;
 
-    auto step = [&](const void* Kc, const void* Vc, int s) {
-        return fa2_forward_step(Q_local, Kc, Vc, O_local, L_local, acc, M, B, H, local_seq_len,
-                                local_seq_len, head_dim, softmax_scale, dtype,
-                                s == 0 ? 1 : 0, s == P - 1 ? 1 : 0, stream);
+    const int half = local_seq_len / 2;
+    auto step = [&](const void* Kc, const void* Vc, int s) -> int {
+        if (!causal)
+            return fa2_forward_step(Q_local, Kc, Vc, O_local, L_local, acc, M, B, H, local_seq_len,
+                                    local_seq_len, head_dim, softmax_scale, dtype,
+                                    s == 0 ? 1 : 0, s == P - 1 ? 1 : 0, stream);
+        const int owner = (rank - s + P) % P;
+        if (owner == rank)            // local block: causal over the local row order
+            return fa2_forward_step_strided(Q_local, Kc, Vc, O_local, L_local, acc, M, B, H, local_seq_len, local_seq_len,
+                                            head_dim, softmax_scale, dtype, 1, 0, 0, 0, 1, 0, stream);
+        if (owner < rank)             // the owner's first chunk, visible to every local row
+            return fa2_forward_step_strided(Q_local, Kc, Vc, O_local, L_local, acc, M, B, H, local_seq_len, half, head_dim,
+                                            softmax_scale, dtype, 0, 0, 0, local_seq_len, 0, 0, stream);
+        // both of the owner's chunks, visible to the rows of the local second chunk only
+        const size_t ro = (size_t)half, eo = ro * head_dim;
+        return fa2_forward_step_strided((const char*)Q_local + eo * 2, Kc, Vc, (char*)O_local + eo * 2, L_local + ro, acc + eo,
+                                        M + ro, B, H, half, local_seq_len, head_dim, softmax_scale, dtype, 0, 0,
+                                        local_seq_len, 0, 0, 0, stream);
+    };
+    auto finish = [&]() -> int {
+        if (!causal) return FA2_OK;
+        return fa2_forward_state_finalize(O_local, L_local, acc, M, (size_t)B * H * local_seq_len, head_dim, dtype, stream);
     };
 
-    if (P == 1) return step(K_local, V_local, 0);
+    if (P == 1) { int st1 = step(K_local, V_local, 0); return st1 ? st1 : finish(); }
 
     // the comm stream may touch the workspace / read the inputs only after everything the
     // caller queued before this call
@@ -231,7 +260,7 @@ int fa2_ring_attention_forward(fa2_ring_ctx* c,
             if (st) return st;
             if (s < P - 1) RING_HIP(hipEventRecord(c->ev_comp[s], stream));
         }
-        return FA2_OK;
+        return finish();
     }
 
     // FA2_RING_MESH: step s computes on the shard owned by rank - s (the relay's order), fetched
@@ -263,7 +292,31 @@ int fa2_ring_attention_forward(fa2_ring_ctx* c,
         st = step(slotK(s - 1), slotV(s - 1), s);
         if (st) return st;
     }
-    return FA2_OK;
+    return finish();
+}
+
+extern "C" {
+
+int fa2_ring_attention_forward(fa2_ring_ctx* c,
+                               const void* Q_local, const void* K_local, const void* V_local,
+                               void* O_local, float* L_local,
+                               int B, int H, int total_seq_len, int local_seq_len, int head_dim,
+                               float softmax_scale, int dtype, int schedule,
+                               void* workspace, size_t workspace_bytes, void* stream)
+{
+    return ring_forward_impl(c, Q_local, K_local, V_local, O_local, L_local, B, H, total_seq_len, local_seq_len, head_dim,
+                             softmax_scale, dtype, schedule, 0, workspace, workspace_bytes, stream);
+}
+
+int fa2_ring_attention_forward_causal(fa2_ring_ctx* c,
+                                      const void* Q_local, const void* K_local, const void* V_local,
+                                      void* O_local, float* L_local,
+                                      int B, int H, int total_seq_len, int local_seq_len, int head_dim,
+                                      float softmax_scale, int dtype, int schedule,
+                                      void* workspace, size_t workspace_bytes, void* stream)
+{
+    return ring_forward_impl(c, Q_local, K_local, V_local, O_local, L_local, B, H, total_seq_len, local_seq_len, head_dim,
+                             softmax_scale, dtype, schedule, 1, workspace, workspace_bytes, stream);
 }
 
 int ring_attention_forward(const float* Q_local, float* K_local, float* V_local,

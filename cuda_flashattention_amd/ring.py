@@ -39,6 +39,7 @@ RING_SIGNATURES = {
     "fa2_ring_ctx_destroy": (_i, [_vp]),
     "fa2_ring_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "fa2_ring_attention_forward": (_i, [_vp] * 6 + [_i, _i, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp]),
+    "fa2_ring_attention_forward_causal": (_i, [_vp] * 6 + [_i, _i, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp]),
     "ring_attention_forward": (_i, [_vp] * 5 + [_i, _i, _i, _f, _vp, _i, _i]),
     "fa2_ring_exchange_kv": (_i, [_vp] * 5 + [_sz, _vp]),
 }
@@ -79,6 +80,16 @@ def shard_rows(total_seq_len, rank, nranks):
     return rank * n, (rank + 1) * n
 
 
+def zigzag_rows(total_seq_len, rank, nranks):
+    """Global row indices of rank's local rows under the causal ring's zig-zag sharding: chunk `rank` then
+    chunk 2P-1-rank of the 2P chunks of N/(2P) rows (fa2_ring_attention_forward_causal)."""
+    if total_seq_len % (2 * nranks) != 0:
+        raise ValueError("seq_len must be divisible by 2 * nranks!")
+    c = total_seq_len // (2 * nranks)
+    a, b = rank, 2 * nranks - 1 - rank
+    return list(range(a * c, (a + 1) * c)) + list(range(b * c, (b + 1) * c))
+
+
 def kv_owner(rank, step, nranks):
     """Owner of the K/V shard rank computes on at `step` (ring_attention_kernel.cu:198)."""
     return (rank - step + nranks) % nranks
@@ -114,10 +125,11 @@ class RingContext:
 
 
 def ring_attention_forward(ctx, Q_local, K_local, V_local, softmax_scale=None, schedule="relay",
-                           O_local=None, L_local=None, stream=None):
+                           O_local=None, L_local=None, stream=None, causal=False):
     """O_local, L_local for this rank's rows.  Mirrors ring_attention_forward(Q_local, K_local,
     V_local, O_local, L_local, total_seq_len, local_seq_len, head_dim, scale, comm, rank, nranks);
-    tensors [B,H,N/P,d] (or [N/P,d]).  K_local / V_local are left intact."""
+    tensors [B,H,N/P,d] (or [N/P,d]).  K_local / V_local are left intact.  causal=True: the local rows
+    are the rank's two zig-zag chunks (zigzag_rows); bf16 only."""
     if Q_local.dim() == 2:
         B, H = 1, 1
         n, d = Q_local.shape
@@ -132,7 +144,8 @@ def ring_attention_forward(ctx, Q_local, K_local, V_local, softmax_scale=None, s
         L_local = torch.empty(Q_local.shape[:-1], dtype=torch.float32, device=Q_local.device)
     ws = ctx.workspace(B, H, n, d, code, sched, Q_local.device)
     s = stream if stream is not None else torch.cuda.current_stream()
-    st = ring_lib().fa2_ring_attention_forward(
+    fn = ring_lib().fa2_ring_attention_forward_causal if causal else ring_lib().fa2_ring_attention_forward
+    st = fn(
         ctx._h, Q_local.data_ptr(), K_local.data_ptr(), V_local.data_ptr(), O_local.data_ptr(),
         L_local.data_ptr(), B, H, n * ctx.nranks, n, d, scale, code, sched,
         ws.data_ptr(), ws.numel(), s.cuda_stream)
@@ -179,6 +192,78 @@ def ring_attention_forward_p2p(dist, Q_local, K_local, V_local, softmax_scale=No
             r.wait()
         if step < P - 1:
             cur_k, cur_v = rk, rv
+    return O, L
+
+
+# ------------------------------------------------------------------------------------------
+# The causal zig-zag schedule over torch.distributed point-to-point ops
+# ------------------------------------------------------------------------------------------
+def _gpu_block(Q, K, V, O, L, Oacc, M, scale, kind):
+    """One block of the causal ring on the HIP step kernel (bf16 [B,H,2c,d] tensors):
+    "local": causal over the local rows, starts the state; "first_keys": the first chunk of K/V against every
+    local row; "second_rows": all of K/V against the rows of the second local chunk."""
+    lib = _capi.lib()
+    B, H, n, d = Q.shape
+    c = n // 2
+    s = torch.cuda.current_stream().cuda_stream
+    if kind == "local":
+        st = lib.fa2_forward_step_strided(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), L.data_ptr(),
+                                          Oacc.data_ptr(), M.data_ptr(), B, H, n, n, d, scale, FA2_DTYPE_BF16, 1, 0, 0, 0, 1, 0, s)
+    elif kind == "first_keys":
+        st = lib.fa2_forward_step_strided(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), L.data_ptr(),
+                                          Oacc.data_ptr(), M.data_ptr(), B, H, n, c, d, scale, FA2_DTYPE_BF16, 0, 0, 0, n, 0, 0, s)
+    else:
+        e = c * d
+        st = lib.fa2_forward_step_strided(Q.data_ptr() + 2 * e, K.data_ptr(), V.data_ptr(), O.data_ptr() + 2 * e,
+                                          L.data_ptr() + 4 * c, Oacc.data_ptr() + 4 * e, M.data_ptr() + 4 * c,
+                                          B, H, c, n, d, scale, FA2_DTYPE_BF16, 0, 0, n, 0, 0, 0, s)
+    check(st, "fa2_forward_step_strided")
+
+
+def _gpu_finalize(O, L, Oacc, M):
+    B, H, n, d = O.shape
+    check(_capi.lib().fa2_forward_state_finalize(O.data_ptr(), L.data_ptr(), Oacc.data_ptr(), M.data_ptr(), B * H * n, d,
+                                                 FA2_DTYPE_BF16, torch.cuda.current_stream().cuda_stream),
+          "fa2_forward_state_finalize")
+
+
+def causal_block_kind(rank, owner):
+    """Which block of the zig-zag causal ring rank computes while owner's shard is resident."""
+    return "local" if owner == rank else ("first_keys" if owner < rank else "second_rows")
+
+
+def ring_attention_forward_causal_p2p(dist, Q_local, K_local, V_local, softmax_scale=None, block_fn=None,
+                                      finalize_fn=None, group=None):
+    """fa2_ring_attention_forward_causal's relay schedule over torch.distributed P2P ops (zig-zag sharded
+    local rows, see zigzag_rows).  block_fn(Q, K, V, O, L, Oacc, M, scale, kind) folds one block into the
+    state, finalize_fn(O, L, Oacc, M) turns the state into results; defaults: the HIP kernels."""
+    rank, P = dist.get_rank(group), dist.get_world_size(group)
+    d = Q_local.shape[-1]
+    scale = float(softmax_scale) if softmax_scale is not None else 1.0 / math.sqrt(d)
+    block_fn = block_fn or _gpu_block
+    finalize_fn = finalize_fn or _gpu_finalize
+    O = torch.empty_like(Q_local)
+    L = torch.empty(Q_local.shape[:-1], dtype=torch.float32, device=Q_local.device)
+    M = torch.empty_like(L)
+    Oacc = torch.empty(Q_local.shape, dtype=torch.float32, device=Q_local.device)
+    nxt, prv = (rank + 1) % P, (rank - 1 + P) % P
+    if group is not None:
+        nxt, prv = dist.get_global_rank(group, nxt), dist.get_global_rank(group, prv)
+    cur_k, cur_v = K_local, V_local
+    spare = [(torch.empty_like(K_local), torch.empty_like(V_local)) for _ in range(min(2, P - 1))]
+    for step in range(P):
+        reqs = []
+        if step < P - 1:
+            rk, rv = spare[step % len(spare)]
+            ops = [dist.P2POp(dist.isend, cur_k, nxt, group), dist.P2POp(dist.irecv, rk, prv, group),
+                   dist.P2POp(dist.isend, cur_v, nxt, group), dist.P2POp(dist.irecv, rv, prv, group)]
+            reqs = dist.batch_isend_irecv(ops)
+        block_fn(Q_local, cur_k, cur_v, O, L, Oacc, M, scale, causal_block_kind(rank, kv_owner(rank, step, P)))
+        for r in reqs:
+            r.wait()
+        if step < P - 1:
+            cur_k, cur_v = rk, rv
+    finalize_fn(O, L, Oacc, M)
     return O, L
 
 

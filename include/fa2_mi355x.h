@@ -125,6 +125,23 @@ int fa2_forward_step(const void* Q, const void* K, const void* V,
                      int B, int H, int q_len, int kv_len, int head_dim, float softmax_scale,
                      int dtype, int first, int last, void* stream);
 
+/* fa2_forward_step (bf16 only) over a ROW RANGE of every head: consecutive heads are q_head_stride rows
+ * apart in Q / O / Oacc / L / M and kv_head_stride rows apart in K / V (0 = q_len / kv_len, dense); the
+ * pointers address the first row of the range in head 0.  With causal != 0 key j is visible to local
+ * query i iff j <= i + causal_shift.  This is the unit of work of the causal zig-zag ring, where a
+ * step folds half of the local keys into all local rows, or all of them into half of the rows. */
+int fa2_forward_step_strided(const void* Q, const void* K, const void* V,
+                             void* O, float* L, float* Oacc, float* M,
+                             int B, int H, int q_len, int kv_len, int head_dim, float softmax_scale,
+                             int dtype, int first, int last, int q_head_stride, int kv_head_stride,
+                             int causal, int causal_shift, void* stream);
+
+/* Turns the bf16 step state of `rows` consecutive rows into results: O = acc / l (bf16), L = m + ln l
+ * (on entry L holds l) -- what last != 0 does inside a step, for schedules whose last step does not
+ * touch every row. */
+int fa2_forward_state_finalize(void* O, float* L, const float* Oacc, const float* M,
+                               size_t rows, int head_dim, int dtype, void* stream);
+
 /* Element-wise helpers (grid-stride, HBM-bound). */
 int fa2_fill_f32(float* dst, size_t n, float value, void* stream);      /* init_array, cuda_helper.h:60-65 */
 int fa2_convert_f32_to_bf16(const float* src, void* dst, size_t n, void* stream);

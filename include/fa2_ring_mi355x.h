@@ -73,6 +73,18 @@ int fa2_ring_attention_forward(fa2_ring_ctx* ctx,
                                float softmax_scale, int dtype, int schedule,
                                void* workspace, size_t workspace_bytes, void* stream);
 
+/* Causal ring forward, load-balanced ("zig-zag") sharding -- past the reference, whose ring is non-causal
+ * (SURVEY 8f rank 2).  The sequence is cut into 2 * nranks chunks of local_seq_len / 2 rows; rank r holds
+ * chunk r in its local rows [0, local/2) and chunk 2 * nranks - 1 - r in rows [local/2, local): every step
+ * after the first then costs half a dense block on every rank.  bf16 only; local_seq_len must be even.  Same
+ * workspace, schedules and stream rules as fa2_ring_attention_forward. */
+int fa2_ring_attention_forward_causal(fa2_ring_ctx* ctx,
+                                      const void* Q_local, const void* K_local, const void* V_local,
+                                      void* O_local, float* L_local,
+                                      int B, int H, int total_seq_len, int local_seq_len, int head_dim,
+                                      float softmax_scale, int dtype, int schedule,
+                                      void* workspace, size_t workspace_bytes, void* stream);
+
 /* Reference-signature drop-in (ring_attention_kernel.cu:143-156): single head, fp32, `comm` is the
  * caller's ncclComm_t.  Allocates its scratch per call as the reference does, synchronises the
  * device before returning, and -- unlike the reference -- leaves K_local / V_local intact. */

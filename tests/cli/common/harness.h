@@ -82,6 +82,47 @@ inline void to_bf16(const std::vector<float>& src, std::vector<uint16_t>& dst, s
     }
 }
 
+// ---- OCP e4m3 (fp8) <-> f32 on the host: round to nearest even, saturating at +-448 (0x7f / 0xff are NaN)
+inline uint8_t f2e4m3(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    const uint8_t sign = (uint8_t)((u >> 31) << 7);
+    const float a = std::fabs(f);
+    if (a != a) return sign | 0x7f;
+    if (a >= 464.0f) return sign | 0x7e;                       // beyond 448 + half an ulp
+    int e;
+    const float m = std::frexp(a, &e);                         // a = m 2^e, m in [0.5, 1)
+    int E = e - 1;                                             // a = (2m) 2^E
+    if (a == 0.0f) return sign;
+    if (E < -6) {                                              // subnormal: multiples of 2^-9
+        const int r = (int)std::nearbyint(a * 512.0f);
+        return sign | (uint8_t)r;                              // r == 8 is the smallest normal, 0x08
+    }
+    int r = (int)std::nearbyint((2.0f * m - 1.0f) * 8.0f);
+    if (r == 8) { r = 0; ++E; }
+    if (E > 8 || (E == 8 && r == 7)) return sign | 0x7e;
+    return sign | (uint8_t)(((E + 7) << 3) | r);
+}
+inline float e4m32f(uint8_t b)
+{
+    const int E = (b >> 3) & 15, r = b & 7;
+    float v;
+    if (E == 15 && r == 7) v = NAN;
+    else if (E == 0) v = std::ldexp((float)r, -9);
+    else v = std::ldexp(1.0f + r / 8.0f, E - 7);
+    return (b & 0x80) ? -v : v;
+}
+inline void to_e4m3(const std::vector<float>& src, std::vector<uint8_t>& dst, std::vector<float>* rounded = nullptr)
+{
+    dst.resize(src.size());
+    if (rounded) rounded->resize(src.size());
+    for (size_t i = 0; i < src.size(); ++i) {
+        dst[i] = f2e4m3(src[i]);
+        if (rounded) (*rounded)[i] = e4m32f(dst[i]);
+    }
+}
+
 // ---- device buffers
 template <typename T>
 struct DevBuf {
@@ -226,6 +267,7 @@ struct GpuTimer {
     }
 };
 
+constexpr double kPeakFp8Tflops = 5033.2;    // MI355X dense fp8 MFMA (twice the bf16 rate)
 constexpr double kPeakBf16Tflops = 2516.6;   // MI355X dense bf16 MFMA (256 CU x 4096 flop/clk x 2.4 GHz)
 
 inline void print_device()

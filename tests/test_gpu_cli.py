@@ -44,6 +44,8 @@ def test_02_forward_shape_args():
     assert rc == 0 and "Test PASSED" in out and "TFLOP/s" in out, out
     rc, out = run("02_flash_attention_v2_forward", 1, 2, 777, 64, 1, 2)
     assert rc == 0 and "Test PASSED" in out, out
+    rc, out = run("02_flash_attention_v2_forward", 1, 2, 1000, 128, 1, 2, "fp8")      # BASELINE configs[4] path
+    assert rc == 0 and "Test PASSED" in out and "fp8-e4m3" in out, out
 
 
 def test_02_backward_reference_cases():

@@ -68,3 +68,61 @@ def test_ring_reference_signature_fp32_single_rank(golden):
     finally:
         rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+@pytest.mark.parametrize("P,B,H,N,d", [(2, 1, 2, 512, 128), (4, 1, 3, 1024, 64), (8, 2, 8, 2048, 128)])
+def test_causal_zigzag_blocks_on_one_gpu(P, B, H, N, d):
+    """The causal ring's per-rank work -- the strided / causal step kernel and the finalize pass -- for P
+    virtual ranks played one after the other on this GPU (the K/V 'exchange' is a pointer), against the
+    single-GPU causal forward on the same inputs.  (The RCCL transport itself needs P GPUs.)"""
+    import cuda_flashattention_amd as fa
+    from cuda_flashattention_amd import ring
+    g = torch.Generator().manual_seed(5)
+    mk = lambda: (torch.rand(B, H, N, d, generator=g) - 0.5).bfloat16().cuda()
+    Q, K, V = mk(), mk(), mk()
+    s = 1.0 / d ** 0.5
+    Oref, Lref = fa.flash_attention_2_forward(Q, K, V, s, causal=True)
+    O = torch.empty_like(Q)
+    L = torch.empty(B, H, N, device="cuda")
+    shards = []
+    for r in range(P):
+        rows = torch.tensor(ring.zigzag_rows(N, r, P), device="cuda")
+        shards.append((rows, Q[:, :, rows].contiguous(), K[:, :, rows].contiguous(), V[:, :, rows].contiguous()))
+    for r in range(P):
+        rows, Ql, _, _ = shards[r]
+        Ol = torch.empty_like(Ql)
+        Ll = torch.empty(B, H, Ql.shape[2], device="cuda")
+        Ml = torch.empty_like(Ll)
+        Oacc = torch.empty(Ql.shape, dtype=torch.float32, device="cuda")
+        for step in range(P):
+            owner = ring.kv_owner(r, step, P)
+            ring._gpu_block(Ql, shards[owner][2], shards[owner][3], Ol, Ll, Oacc, Ml, s, ring.causal_block_kind(r, owner))
+        ring._gpu_finalize(Ol, Ll, Oacc, Ml)
+        O[:, :, rows] = Ol
+        L[:, :, rows] = Ll
+    torch.cuda.synchronize()
+    a, b = O.float().cpu().numpy(), Oref.float().cpu().numpy()
+    # two bf16 evaluations with different block orders: each carries the bf16 rounding of P (2e-3 against the
+    # oracle), so they differ by about sqrt(2) of that; L comes from fp32 sums and must agree closely
+    assert np.linalg.norm(a - b) / np.linalg.norm(b) <= 5e-3
+    assert np.abs(L.cpu().numpy() - Lref.cpu().numpy()).max() <= 1e-4
+
+
+def test_causal_ring_one_rank_is_local_causal():
+    import cuda_flashattention_amd as fa
+    from cuda_flashattention_amd import ring
+    B, H, N, d = 1, 4, 768, 128
+    g = torch.Generator().manual_seed(6)
+    mk = lambda: (torch.rand(B, H, N, d, generator=g) - 0.5).bfloat16().cuda()
+    Q, K, V = mk(), mk(), mk()
+    ctx = ring.RingContext(None, 0, 1)
+    try:
+        O, L = ring.ring_attention_forward(ctx, Q, K, V, causal=True)
+        Oref, Lref = fa.flash_attention_2_forward(Q, K, V, causal=True)
+        torch.cuda.synchronize()
+        assert np.linalg.norm((O.float() - Oref.float()).cpu().numpy()) / np.linalg.norm(Oref.float().cpu().numpy()) <= 1e-3
+        assert (L - Lref).abs().max().item() <= 1e-4
+        with pytest.raises(fa._capi.FA2Error):          # fp32 has no causal ring
+            ring.ring_attention_forward(ctx, Q.float(), K.float(), V.float(), causal=True)
+    finally:
+        ctx.close()

@@ -99,3 +99,88 @@ def test_shard_helpers():
         for r in range(P):
             owners = [ring.kv_owner(r, s, P) for s in range(P)]
             assert owners[0] == r and sorted(owners) == list(range(P))
+
+
+# ----------------------------------------------------------------------------- causal zig-zag ring
+def _oracle_causal_block(Q, K, V, O, L, Oacc, M, scale, kind):
+    """block_fn for ring_attention_forward_causal_p2p on CPU fp32 tensors [2c, d].  State in (O, L, M) as in
+    _oracle_step.  "local": exact causal attention over the local rows, stored as the equivalent state
+    (acc = O, l = 1, m = LSE); the other two blocks are plain ring steps on row slices."""
+    import oracle
+    n = Q.shape[0]
+    c = n // 2
+    if kind == "local":
+        o, lse = oracle.attention_forward(Q.numpy(), K.numpy(), V.numpy(), float(scale), causal=True)
+        O.copy_(torch.from_numpy(np.asarray(o, dtype=np.float32)))
+        M.copy_(torch.from_numpy(np.asarray(lse, dtype=np.float32)))
+        L.fill_(1.0)
+    elif kind == "first_keys":
+        oracle.ring_step(Q.numpy(), K[:c].numpy(), V[:c].numpy(), O.numpy(), L.numpy(), M.numpy(), float(scale), False)
+    else:
+        oracle.ring_step(Q[c:].numpy(), K.numpy(), V.numpy(), O[c:].numpy(), L[c:].numpy(), M[c:].numpy(), float(scale), False)
+
+
+def _oracle_finalize(O, L, Oacc, M):
+    O /= L[:, None]
+    L.copy_(M + torch.log(L))
+
+
+def _causal_worker(rank, world, port, N, d, scale, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cuda_flashattention_amd import ring
+        rng = np.random.default_rng(1)
+        Q, K, V = (rng.uniform(-0.5, 0.5, (N, d)).astype(np.float32) for _ in range(3))
+        rows = ring.zigzag_rows(N, rank, world)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a[rows]))
+        O, L = ring.ring_attention_forward_causal_p2p(dist, t(Q), t(K), t(V), scale, block_fn=_oracle_causal_block,
+                                                      finalize_fn=_oracle_finalize)
+        go = [torch.empty_like(O) for _ in range(world)]
+        gl = [torch.empty_like(L) for _ in range(world)]
+        dist.all_gather(go, O)
+        dist.all_gather(gl, L)
+        if rank == 0:
+            Of = np.empty((N, d), np.float32)
+            Lf = np.empty(N, np.float32)
+            for r in range(world):                      # undo the zig-zag order
+                rr = ring.zigzag_rows(N, r, world)
+                Of[rr] = go[r].numpy()
+                Lf[rr] = gl[r].numpy()
+            ret["O"], ret["L"] = Of, Lf
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,N,d", [(2, 128, 32), (3, 96, 16)])
+def test_causal_zigzag_ring_matches_one_shot(world, N, d):
+    """Causal ring with zig-zag sharding (past the reference): every rank's blocks --
+    local causal, first-chunk keys for all rows, all keys for the second-chunk rows -- add up to causal
+    attention over the whole sequence.  No counterpart in the reference: pinned by the oracle's own
+    masked-dense causal forward."""
+    import oracle
+    scale = 1.0 / np.sqrt(d)
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_causal_worker, args=(world, _free_port(), N, d, scale, ret), nprocs=world, join=True)
+        O, L = ret["O"], ret["L"]
+    rng = np.random.default_rng(1)
+    Q, K, V = (rng.uniform(-0.5, 0.5, (N, d)).astype(np.float32) for _ in range(3))
+    Or, Lr = oracle.attention_forward(Q, K, V, float(scale), causal=True)
+    assert np.abs(O - Or).max() < 5e-6
+    assert np.abs(L - Lr).max() < 5e-6
+
+
+def test_zigzag_helpers():
+    from cuda_flashattention_amd import ring
+    for P in (1, 2, 4, 8):
+        N = 16 * P
+        seen = sorted(i for r in range(P) for i in ring.zigzag_rows(N, r, P))
+        assert seen == list(range(N))                   # a partition of the sequence
+        for r in range(P):
+            kinds = [ring.causal_block_kind(r, ring.kv_owner(r, s, P)) for s in range(P)]
+            assert kinds[0] == "local" and kinds.count("local") == 1
+            assert kinds.count("first_keys") == r and kinds.count("second_rows") == P - 1 - r
+    with pytest.raises(ValueError):
+        ring.zigzag_rows(100, 0, 3)
