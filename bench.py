@@ -33,13 +33,13 @@ PEAK_BF16_TFLOPS = 2516.6   # MI355X dense bf16 MFMA: 256 CU x 4096 flop/clk x 2
 # operands (tools/probes/mfma_power.hip): the clock settles near 1.77 GHz.  Reported beside the
 # nominal peak; `frac` is always against the nominal one.
 SUSTAINED_MFMA_TFLOPS = 1840.0
-# HBM bytes per launch from the PMC passes in profiles/r1_c_pmc_summary.txt (FETCH_SIZE doubled as
+# HBM bytes per launch from the PMC passes in profiles/r1_d_pmc_summary.txt (FETCH_SIZE doubled as
 # MI355X_MICROARCH.md prescribes for gfx950, plus WRITE_SIZE; units of 1024 B).  Collected with
 # rocprofv3 in separate passes, not inside this script.
 PMC_TRAFFIC_BYTES = {
-    "fa2_fwd_bf16_kernel": (2 * 196840 + 133120) * 1024,
-    "fa2_bwd_dq_kernel": (2 * 264346 + 131072) * 1024,
-    "fa2_bwd_dkdv_kernel": (2 * 268472 + 270369) * 1024,
+    "fa2_fwd_bf16_kernel": (2 * 196905 + 133120) * 1024,
+    "fa2_bwd_dq_kernel": (2 * 264344 + 131072) * 1024,
+    "fa2_bwd_dkdv_kernel": (2 * 268507 + 270352) * 1024,
 }
 B, H, N, D = 4, 16, 8192, 128
 

@@ -56,44 +56,10 @@ __device__ __forceinline__ bf16x8 lds_read_frag(const char* base, int byte_off)
     return *reinterpret_cast<const bf16x8*>(base + byte_off);
 }
 
-// Transposed read.  Within each group of 16 lanes, lane 4q+p supplies the address of row q,
-// columns 4p..4p+3 of a 4-row x 16-column block; lane i of the group receives column i of
-// the 4 rows (row q in element q).  EXEC must be all ones (never call under divergence).
-__device__ __forceinline__ bf16x4 lds_read_tr(const char* base, int byte_off)
-{
-    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-        (lds_bf16x4*)(uintptr_t)(uint32_t)(uintptr_t)(base + byte_off));
-}
-
-// The same read issued from inline asm, for loops that keep an LDS-DMA (buffer_load ... lds) in
-// flight: hipcc puts `s_waitcnt vmcnt(0)` in front of the tr-read BUILTIN whenever a DMA is
-// pending (it cannot tell the two apart), which exposes the whole DMA latency.  The asm form is
-// invisible to that logic; in exchange its completion must be waited for by hand with
-// lds_tr_wait<N>() naming every destination (so no compiler copy can run ahead of the data).
-// `addr` is the lane's LDS byte address, IMM a compile-time byte offset (< 65536).
-template <int IMM>
-__device__ __forceinline__ bf16x4 lds_read_tr_asm(uint32_t addr)
-{
-    bf16x4 r;
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(IMM));
-    return r;
-}
-// Waits until at most N LDS operations of this wave are outstanding (they return in order).
-template <int N>
-__device__ __forceinline__ void lds_tr_wait(bf16x4& a, bf16x4& b, bf16x4& c, bf16x4& d)
-{
-    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(N));
-}
-
 template <int N>
 __device__ __forceinline__ void lds_tr_wait2(bf16x4& a, bf16x4& b)
 {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "i"(N));
-}
-
-__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c)
-{
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
 // Accumulate into a tile that must live in the accumulator half of the register file.  In the
@@ -151,12 +117,6 @@ __device__ __forceinline__ void static_for(F&& f)
     static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-template <int LO>
-__device__ __forceinline__ void acc_mfma(bf16x8 a, bf16x8 b)
-{
-    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]"
-                 : : "v"(a), "v"(b), "i"(LO), "i"(LO + 15) : FA2_ACC_CLOBBERS);
-}
 // Product whose B operand is a fragment resident in literal AGPRs a[BLO : BLO+3] (an operand that
 // never changes during the kernel, e.g. the Q fragments of a query block) and whose accumulator is
 // an ordinary VGPR tile the VALU reads afterwards: c += a * a[BLO:BLO+3].  Whoever reads c with
@@ -166,12 +126,6 @@ __device__ __forceinline__ void mfma_bagpr(f32x16& c, bf16x8 a)
 {
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0"
                  : "+v"(c) : "v"(a), "i"(BLO), "i"(BLO + 3) : FA2_ACC_CLOBBERS);
-}
-// All-VGPR product issued from asm (c += a * b), for loops whose MFMA order is hand-placed: being
-// volatile it keeps its position among the other asm statements, which builtin MFMAs do not.
-__device__ __forceinline__ void mfma_vv(f32x16& c, bf16x8 a, bf16x8 b)
-{
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 
 // Two all-VGPR products sharing their A operand in one statement: c0 += a * b0, c1 += a * b1.
@@ -186,25 +140,7 @@ __device__ __forceinline__ void mfma2_vv(f32x16& c0, f32x16& c1, bf16x8 a, bf16x
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %4, %5, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %4, %6, %1"
                  : "+v"(c0), "+v"(c1), "+v"(dep0), "+v"(dep1) : "v"(a), "v"(b0), "v"(b1));
 }
-// Two accumulations into hipcc-allocated AGPR tiles sharing their A operand (see mfma32_acc).
-__device__ __forceinline__ void mfma2_acc(f32x16& c0, f32x16& c1, bf16x8 a, bf16x8 b0, bf16x8 b1)
-{
-    asm volatile("s_nop 0\n\tv_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %2, %4, %1"
-                 : "+a"(c0), "+a"(c1) : "v"(a), "v"(b0), "v"(b1));
-}
-__device__ __forceinline__ void mfma2_acc(f32x16& c0, f32x16& c1, bf16x8 a, bf16x8 b0, bf16x8 b1, f32x16& dep0, f32x16& dep1)
-{
-    asm volatile("s_nop 0\n\tv_mfma_f32_32x32x16_bf16 %0, %4, %5, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %4, %6, %1"
-                 : "+a"(c0), "+a"(c1), "+v"(dep0), "+v"(dep1) : "v"(a), "v"(b0), "v"(b1));
-}
 
-// First product of a chain: c = a * a[BLO:BLO+3] (C = 0 inline constant: no zero-fill of the tile).
-template <int BLO>
-__device__ __forceinline__ void mfma_bagpr_init(f32x16& c, bf16x8 a)
-{
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0"
-                 : "=&v"(c) : "v"(a), "i"(BLO), "i"(BLO + 3) : FA2_ACC_CLOBBERS);
-}
 // One k-step of two products that share their streamed A operands, in ONE asm statement (every
 // asm boundary costs a pad s_nop from hipcc, and the loops that use these are issue-bound):
 //   s0 += ka * a[Q0..]   s1 += ka * a[Q1..]   d0 += va * a[G0..]   d1 += va * a[G1..]
@@ -250,36 +186,6 @@ __device__ __forceinline__ void mfma4_bagpr_init(f32x16& s0, f32x16& s1, f32x16&
                    "i"(Q0), "i"(Q0 + 3), "i"(Q1), "i"(Q1 + 3), "i"(G0), "i"(G0 + 3), "i"(G1), "i"(G1 + 3)
                  : FA2_ACC_CLOBBERS);
 }
-// Two products sharing the streamed A operand, B operands resident in AGPRs: s0 += a * a[Q0..], s1 += a * a[Q1..].
-template <int Q0, int Q1>
-__device__ __forceinline__ void mfma2_bagpr(f32x16& s0, f32x16& s1, bf16x8 a)
-{
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, a[%c3:%c4], %0\n\tv_mfma_f32_32x32x16_bf16 %1, %2, a[%c5:%c6], %1"
-                 : "+v"(s0), "+v"(s1) : "v"(a), "i"(Q0), "i"(Q0 + 3), "i"(Q1), "i"(Q1 + 3) : FA2_ACC_CLOBBERS);
-}
-template <int Q0, int Q1>
-__device__ __forceinline__ void mfma2_bagpr_init(f32x16& s0, f32x16& s1, bf16x8 a)
-{
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, a[%c3:%c4], 0\n\tv_mfma_f32_32x32x16_bf16 %1, %2, a[%c5:%c6], 0"
-                 : "=&v"(s0), "=&v"(s1) : "v"(a), "i"(Q0), "i"(Q0 + 3), "i"(Q1), "i"(Q1 + 3) : FA2_ACC_CLOBBERS);
-}
-__device__ __forceinline__ void thread2(f32x16& a, f32x16& b) { asm volatile("" : "+v"(a), "+v"(b)); }
-// mfma2_bagpr threading two finished tiles (read beside this statement) and two scalars (partial
-// results that must be complete before the next statement).
-template <int Q0, int Q1>
-__device__ __forceinline__ void mfma2_bagpr(f32x16& s0, f32x16& s1, bf16x8 a, f32x16& dep0, f32x16& dep1, float& f0, float& f1)
-{
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %6, a[%c7:%c8], %0\n\tv_mfma_f32_32x32x16_bf16 %1, %6, a[%c9:%c10], %1"
-                 : "+v"(s0), "+v"(s1), "+v"(dep0), "+v"(dep1), "+v"(f0), "+v"(f1)
-                 : "v"(a), "i"(Q0), "i"(Q0 + 3), "i"(Q1), "i"(Q1 + 3) : FA2_ACC_CLOBBERS);
-}
-template <int Q0, int Q1>
-__device__ __forceinline__ void mfma2_bagpr_init(f32x16& s0, f32x16& s1, bf16x8 a, f32x16& dep0, f32x16& dep1, float& f0, float& f1)
-{
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %6, a[%c7:%c8], 0\n\tv_mfma_f32_32x32x16_bf16 %1, %6, a[%c9:%c10], 0"
-                 : "=&v"(s0), "=&v"(s1), "+v"(dep0), "+v"(dep1), "+v"(f0), "+v"(f1)
-                 : "v"(a), "i"(Q0), "i"(Q0 + 3), "i"(Q1), "i"(Q1 + 3) : FA2_ACC_CLOBBERS);
-}
 // acc_mfma2 threading TWO dependent tiles.
 template <int LO0, int LO1>
 __device__ __forceinline__ void acc_mfma2(bf16x8 a, bf16x8 b0, bf16x8 b1, f32x16& dep0, f32x16& dep1)
@@ -297,11 +203,6 @@ __device__ __forceinline__ void acc_mfma2(bf16x8 a, bf16x8 b0, bf16x8 b1, f32x16
                  "v_mfma_f32_32x32x16_bf16 a[%c9:%c10], %4, %6, a[%c9:%c10]"
                  : "+v"(dep0), "+v"(dep1), "+v"(f0), "+v"(f1)
                  : "v"(a), "v"(b0), "v"(b1), "i"(LO0), "i"(LO0 + 15), "i"(LO1), "i"(LO1 + 15) : FA2_ACC_CLOBBERS);
-}
-template <typename F>
-__device__ __forceinline__ void thread2f(f32x16& a, f32x16& b, F& f0, F& f1)
-{
-    asm volatile("" : "+v"(a), "+v"(b), "+v"(f0), "+v"(f1));
 }
 // Threads four tiles through the asm order (see mfma4_bagpr) without doing anything.
 __device__ __forceinline__ void thread4(f32x16& a, f32x16& b, f32x16& c, f32x16& d)
@@ -325,48 +226,6 @@ __device__ __forceinline__ void acc_mfma2(bf16x8 a, bf16x8 b0, bf16x8 b1, f32x16
                  "v_mfma_f32_32x32x16_bf16 a[%c9:%c10], %4, %6, a[%c9:%c10]"
                  : "+v"(dep0), "+v"(dep1), "+v"(dep2), "+v"(dep3)
                  : "v"(a), "v"(b0), "v"(b1), "i"(LO0), "i"(LO0 + 15), "i"(LO1), "i"(LO1 + 15) : FA2_ACC_CLOBBERS);
-}
-// One PV group of the forward kernel in ONE statement: the two transposed reads of the NEXT group's
-// V^T fragment (n0, n1), the wait that leaves exactly those two in flight (so the current fragment
-// `a`, read one group earlier, has landed), and the two accumulations a[LO0..] += a * b0,
-// a[LO1..] += a * b1.  No pad s_nop: none of a, b0, b1 may have been written by a VALU instruction
-// within the two instructions before this statement (they come from LDS and from the previous
-// step's packing).  dep0/dep1/f0/f1 are threaded through (see mfma4_bagpr).
-template <int IMM, int LO0, int LO1, typename F>
-__device__ __forceinline__ void pv_group_next(bf16x4& n0, bf16x4& n1, uint32_t addr0, uint32_t addr1, bf16x8 a, bf16x8 b0,
-                                              bf16x8 b1, f32x16& dep0, f32x16& dep1, F& f0, F& f1)
-{
-    asm volatile("ds_read_b64_tr_b16 %0, %6 offset:%c8\n\tds_read_b64_tr_b16 %1, %7 offset:%c8\n\t"
-                 "s_waitcnt lgkmcnt(2)\n\t"
-                 "v_mfma_f32_32x32x16_bf16 a[%c12:%c13], %9, %10, a[%c12:%c13]\n\t"
-                 "v_mfma_f32_32x32x16_bf16 a[%c14:%c15], %9, %11, a[%c14:%c15]"
-                 : "=&v"(n0), "=&v"(n1), "+v"(dep0), "+v"(dep1), "+v"(f0), "+v"(f1)
-                 : "v"(addr0), "v"(addr1), "i"(IMM), "v"(a), "v"(b0), "v"(b1), "i"(LO0), "i"(LO0 + 15), "i"(LO1), "i"(LO1 + 15)
-                 : FA2_ACC_CLOBBERS);
-}
-// The last group of a stage: nothing further to read, wait for everything.
-template <int LO0, int LO1, typename F>
-__device__ __forceinline__ void pv_group_last(bf16x8 a, bf16x8 b0, bf16x8 b1, f32x16& dep0, f32x16& dep1, F& f0, F& f1)
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
-                 "v_mfma_f32_32x32x16_bf16 a[%c7:%c8], %4, %5, a[%c7:%c8]\n\t"
-                 "v_mfma_f32_32x32x16_bf16 a[%c9:%c10], %4, %6, a[%c9:%c10]"
-                 : "+v"(dep0), "+v"(dep1), "+v"(f0), "+v"(f1)
-                 : "v"(a), "v"(b0), "v"(b1), "i"(LO0), "i"(LO0 + 15), "i"(LO1), "i"(LO1 + 15) : FA2_ACC_CLOBBERS);
-}
-// acc += p.lo + p.hi for a packed bf16 pair (v_dot2c_f32_bf16 against a pair of ones): the running
-// row sum is taken over the ROUNDED probabilities, the same values the PV product consumes.
-__device__ __forceinline__ void sum_bf16_pair(float& acc, uint32_t p)
-{
-    asm("v_dot2c_f32_bf16 %0, 0x3f803f80, %1" : "+v"(acc) : "v"(p));
-}
-// Two floats -> one packed bf16 pair (v_cvt_pk_bf16_f32, round to nearest even).
-__device__ __forceinline__ uint32_t pack_bf16_pair(float lo, float hi)
-{
-    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-    const bf16x2_t v = __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t);
-    return __builtin_bit_cast(uint32_t, v);
 }
 
 // Two accumulations into hipcc-allocated AGPR tiles that share their A operand, fused with the two
@@ -412,11 +271,6 @@ __device__ __forceinline__ void lds_read_tr2_asm(bf16x4& r0, bf16x4& r1, uint32_
     asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%4\n\tds_read_b64_tr_b16 %1, %3 offset:%4"
                  : "=&v"(r0), "=&v"(r1) : "v"(addr0), "v"(addr1), "i"(IMM));
 }
-__device__ __forceinline__ void pin4(float& a, float& b, float& c, float& d)
-{
-    asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
-}
-__device__ __forceinline__ void pin2(float& a, float& b) { asm volatile("" : "+v"(a), "+v"(b)); }
 
 __device__ __forceinline__ void mfma_vgpr_settle(f32x16& c)
 {
@@ -445,40 +299,12 @@ __device__ __forceinline__ void acc_write(float x)
 {
     asm volatile("v_accvgpr_write_b32 a[%c1], %0" : : "v"(x), "i"(R) : FA2_ACC_CLOBBERS);
 }
-// a[R .. R+3] *= alpha
-template <int R>
-__device__ __forceinline__ void acc_scale4(float alpha)
-{
-    float t0, t1, t2, t3;
-    asm volatile("v_accvgpr_read_b32 %0, a[%c5]\n\tv_accvgpr_read_b32 %1, a[%c6]\n\t"
-                 "v_accvgpr_read_b32 %2, a[%c7]\n\tv_accvgpr_read_b32 %3, a[%c8]\n\t"
-                 "v_mul_f32 %0, %0, %4\n\tv_mul_f32 %1, %1, %4\n\tv_mul_f32 %2, %2, %4\n\tv_mul_f32 %3, %3, %4\n\t"
-                 "v_accvgpr_write_b32 a[%c5], %0\n\tv_accvgpr_write_b32 a[%c6], %1\n\t"
-                 "v_accvgpr_write_b32 a[%c7], %2\n\tv_accvgpr_write_b32 a[%c8], %3"
-                 : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
-                 : "v"(alpha), "i"(R), "i"(R + 1), "i"(R + 2), "i"(R + 3) : FA2_ACC_CLOBBERS);
-}
-
-// Makes a value opaque at this point of the program: hipcc cannot schedule its producers below
-// or its consumers above this statement, and -- being volatile -- the statement keeps its place
-// among the other asm statements (MFMAs, transposed reads, waits).  Used to pin VALU work between
-// the asm-issued MFMA groups it is meant to run beside.
-__device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
 
 // Keeps an MFMA operand's registers allocated up to this point.  hipcc sees an asm-issued MFMA as
 // an instruction that has read its operands once issued, and may hand a dead operand register to
 // the very next VALU instruction as a temporary -- while the matrix pipe is still reading it
 // (observed: wrong products at D = 64).  Place after the VALU work that follows the MFMA.
 __device__ __forceinline__ void keep_alive(const bf16x8& x) { asm volatile("" : : "v"(x)); }
-
-// Value held by the same lane index in the OTHER 32-lane half of the wave.
-__device__ __forceinline__ float other_half(float x)
-{
-    const uint32_t u = __float_as_uint(x);
-    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    // r[0]: lanes 32-63 now hold lanes 0-31's value; r[1]: lanes 0-31 hold lanes 32-63's.
-    return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
-}
 
 __device__ __forceinline__ float half_max(float x)
 {
