@@ -294,3 +294,34 @@ def test_errors_are_status_codes_not_aborts():
     with pytest.raises(fa._capi.FA2Error) as e:
         fa.flash_attention_2_forward(Q, Q, Q)
     assert e.value.status == -3
+
+
+def test_forward_backward_capture_into_hip_graph():
+    """Nothing inside fa2_forward / fa2_backward allocates or synchronises: a whole
+    fwd+bwd step can be captured into a graph on a side stream and replayed, with bit-identical results."""
+    fa = _fa()
+    B, H, N, d = 1, 4, 1024, 128
+    Q, K, V, dO = (make(B, H, N, d, s).cuda() for s in (21, 22, 23, 24))
+    s = 1.0 / d ** 0.5
+    O, L = fa.flash_attention_2_forward(Q, K, V, s)
+    dQ, dK, dV = fa.flash_attention_2_backward(Q, K, V, O, L, dO, s)
+    torch.cuda.synchronize()
+    ref = [t.clone() for t in (O, L, dQ, dK, dV)]
+    O2, L2 = torch.zeros_like(O), torch.zeros_like(L)
+    dQ2, dK2, dV2 = torch.zeros_like(dQ), torch.zeros_like(dK), torch.zeros_like(dV)
+    ws = torch.empty(fa._capi.lib().fa2_backward_workspace_bytes(B, H, N, d, 0), dtype=torch.uint8, device="cuda")
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            fa.flash_attention_2_forward(Q, K, V, s, O=O2, L=L2)
+            fa.flash_attention_2_backward(Q, K, V, O2, L2, dO, s, dQ=dQ2, dK=dK2, dV=dV2, workspace=ws)
+    torch.cuda.current_stream().wait_stream(side)
+    for _ in range(3):
+        for t in (O2, L2, dQ2, dK2, dV2):
+            t.zero_()
+        graph.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(ref, (O2, L2, dQ2, dK2, dV2)):
+        assert torch.equal(a, b)
