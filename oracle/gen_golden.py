@@ -76,6 +76,14 @@ def main():
                                      np.arange(0, N, 97)]))
     np.savez_compressed(os.path.join(OUT, "k5_ring_pattern_rows.npz"), N=np.int32(N), d=np.int32(d),
                         scale=np.float32(1.0), rows=rows.astype(np.int32), O_rows=O[rows])
+
+    # K6: the literal forward cases of 01_flash_attention_v1/main.cu:195-345, expected outputs from the
+    # reference's naive_attention (00_naive_attention/main.cpp:8-38), the checker that main uses (:155)
+    fa1 = {}
+    for name, Q, K, V in recipes.fa1_cases():
+        fa1[name + "_Q"], fa1[name + "_K"], fa1[name + "_V"] = Q, K, V
+        fa1[name + "_O"] = oracle.naive_attention(Q, K, V, lib=R)
+    np.savez_compressed(os.path.join(OUT, "k6_fa1_cases.npz"), **fa1)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -64,6 +64,29 @@ def naive00():
     return Q, Q.copy(), V, expected
 
 
+def fa1_cases():
+    """The literal forward cases of the superseded FA1 teaching step (01_flash_attention_v1/main.cu:195-345),
+    judged there against naive_attention (scale 1/sqrt(d), main.cpp:8-38) with |diff| <= 1e-3 (:157-163): extra
+    forward known-answer inputs.  Yields (name, Q, K, V) as fp32 [N, d]."""
+    f = lambda rows: np.array(rows, dtype=np.float32)
+    eye4 = np.eye(4, dtype=np.float32)
+    yield "simple_2x4", f([[1, 0, 1, 0], [0, 1, 0, 1]]), f([[1, 0, 1, 0], [0, 1, 0, 1]]), f([[10, 20, 30, 40], [50, 60, 70, 80]])
+    yield "identity_4x4", eye4, eye4, np.diag(np.arange(1, 5)).astype(np.float32)
+    yield "uniform_3x2", np.ones((3, 2), np.float32), np.ones((3, 2), np.float32), f([[1, 2], [3, 4], [5, 6]])
+    yield "orthogonal_2x2", f([[1, 0], [0, 1]]), f([[0, 1], [-1, 0]]), f([[10, 20], [30, 40]])
+    yield "single_element", f([[1]]), f([[1]]), f([[42]])
+    N, d = 8, 4
+    Q = np.zeros((N, d), np.float32)
+    Q[np.arange(d), np.arange(d)] = 1.0                        # (i == j) over an 8 x 4 matrix
+    yield "diagonal_8x4", Q, Q.copy(), (np.arange(N)[:, None] * 10 + np.arange(d)[None, :]).astype(np.float32)
+    N, d = 64, 32
+    x = _draws(42, 3 * N * d).reshape(N * d, 3).astype(np.float32)       # (float)rand()
+    rm = np.float32(2 ** 31 - 1)                                         # RAND_MAX converted to float
+    yield ("random_64x32", (x[:, 0] / rm).reshape(N, d), (x[:, 1] / rm).reshape(N, d),
+           (x[:, 2] / rm * np.float32(100)).reshape(N, d))
+    yield "tiles_4x4", eye4, eye4, np.arange(1, 17, dtype=np.float32).reshape(4, 4)
+
+
 def ring_pattern(N=5096, d=64):
     """util/attention_helper.h:151-173 (create_simple_test_data): Q = K = delta(i, j),
     V[i][j] = 4 i + j + 1."""

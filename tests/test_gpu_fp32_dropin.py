@@ -126,3 +126,20 @@ def test_fp32_extended_vs_oracle(B, H, N, d, causal):
     assert np.abs(L.cpu().numpy() - Lr).max() < 5e-6
     for got, want, k in zip((dQ, dK, dV), gr, ("dQ", "dK", "dV")):
         assert np.abs(got.cpu().numpy() - want).max() < 2e-6, k
+
+
+def test_fa1_literal_cases_through_the_dropin(golden):
+    """The FA1 step's literal forward cases (01_flash_attention_v1/main.cu:195-345, d in {1, 2, 4, 32},
+    N from 1 to 64) through the reference-signature fp32 forward, with that main's own gate |diff| <= 1e-3
+    (:157-163) against the reference's naive_attention outputs (tests/golden/k6_fa1_cases.npz)."""
+    import cuda_flashattention_amd as fa
+    g = golden("k6_fa1_cases.npz")
+    names = sorted({k[:-2] for k in g.files})
+    assert len(names) == 8
+    for name in names:
+        Q, K, V, Oref = (g[name + s] for s in ("_Q", "_K", "_V", "_O"))
+        N, d = Q.shape
+        O, L = fa.flash_attention_2_forward(torch.from_numpy(Q).cuda(), torch.from_numpy(K).cuda(),
+                                            torch.from_numpy(V).cuda(), 1.0 / np.sqrt(d))
+        torch.cuda.synchronize()
+        assert np.abs(O.cpu().numpy() - Oref).max() <= 1e-3, name

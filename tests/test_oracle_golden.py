@@ -162,3 +162,18 @@ def test_oracle_bit_identical_to_reference_build():
         gb = oracle.naive_attention_backward(Q, K, V, dO, float(sc), lib=R)
         assert all(np.array_equal(x, y) for x, y in zip(ga, gb))
         assert np.array_equal(oracle.naive_attention(Q, K, V), oracle.naive_attention(Q, K, V, lib=R))
+
+
+def test_k6_fa1_literal_cases(golden):
+    """01_flash_attention_v1/main.cu:195-345: the superseded FA1 step's literal forward cases, judged there
+    against naive_attention with |diff| <= 1e-3 (extra forward known-answer tests).  The
+    oracle reproduces the reference's outputs bit for bit; the recipes reproduce its inputs."""
+    g = golden("k6_fa1_cases.npz")
+    names = [n for n, *_ in recipes.fa1_cases()]
+    assert len(names) == 8 and {k[:-2] for k in g.files} == set(names)
+    for name, Q, K, V in recipes.fa1_cases():
+        assert np.array_equal(Q, g[name + "_Q"]) and np.array_equal(K, g[name + "_K"]) and np.array_equal(V, g[name + "_V"])
+        assert np.array_equal(oracle.naive_attention(Q, K, V), g[name + "_O"])
+    # closed-form spot checks of the reference outputs themselves
+    assert np.allclose(g["single_element_O"], [[42.0]])
+    assert np.allclose(g["uniform_3x2_O"], np.tile([[3.0, 4.0]], (3, 1)), atol=1e-6)      # uniform weights: the mean of V
