@@ -39,6 +39,7 @@ SIGNATURES = {
     "fa2_forward_step": (_i, [_vp] * 7 + [_i, _i, _i, _i, _i, _f, _i, _i, _i, _vp]),
     "fa2_forward_step_strided": (_i, [_vp] * 7 + [_i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "fa2_forward_state_finalize": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _vp]),
+    "fa2_accumulate_bf16": (_i, [_vp, _vp, _sz, _i, _vp]),
     "fa2_fill_f32": (_i, [_vp, _sz, _f, _vp]),
     "fa2_convert_f32_to_bf16": (_i, [_vp, _vp, _sz, _vp]),
     "fa2_convert_bf16_to_f32": (_i, [_vp, _vp, _sz, _vp]),

@@ -267,6 +267,12 @@ int flash_attention_2_backward(const float* Q, const float* K, const float* V,
                         FA2_DTYPE_F32, 0, ws, need, nullptr);
 }
 
+int fa2_accumulate_bf16(float* acc, const void* src, size_t n, int init, void* stream)
+{
+    if (!acc || !src) return FA2_ERR_NULL_POINTER;
+    return hip_status(fa2::launch_accumulate_bf16(acc, src, n, init, (hipStream_t)stream));
+}
+
 int fa2_fill_f32(float* dst, size_t n, float value, void* stream)
 {
     if (!dst && n) return FA2_ERR_NULL_POINTER;

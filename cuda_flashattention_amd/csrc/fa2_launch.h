@@ -29,6 +29,8 @@ struct FwdArgs {
 };
 
 hipError_t launch_fwd_bf16(const FwdArgs& a, hipStream_t stream);
+// acc (fp32) = (init) or += src (bf16), n elements.
+hipError_t launch_accumulate_bf16(float* acc, const void* src, size_t n, int init, hipStream_t stream);
 // Ring epilogue: O = bf16(Oacc / l), L = m + ln l for `rows` consecutive rows (l arrives in L).
 hipError_t launch_finalize_state(const float* Oacc, const float* M, float* L, void* O, size_t rows, int d, hipStream_t stream);
 

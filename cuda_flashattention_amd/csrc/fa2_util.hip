@@ -111,4 +111,31 @@ hipError_t launch_finalize_state(const float* Oacc, const float* M, float* L, vo
     return hipGetLastError();
 }
 
+// acc (fp32) = or += src (bf16): the ring backward keeps its running gradients in fp32 and adds each step's
+// bf16 contribution to them.
+__global__ void __launch_bounds__(256) accumulate_bf16_kernel(float* acc, const __bf16* src, size_t n, int init)
+{
+    const size_t stride = (size_t)gridDim.x * 256 * 8;
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += stride) {
+        if (i + 8 <= n) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + i);
+            f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+            if (!init) { a0 = *reinterpret_cast<const f32x4*>(acc + i); a1 = *reinterpret_cast<const f32x4*>(acc + i + 4); }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a0[e] += (float)v[e]; a1[e] += (float)v[4 + e]; }
+            *reinterpret_cast<f32x4*>(acc + i) = a0;
+            *reinterpret_cast<f32x4*>(acc + i + 4) = a1;
+        } else {
+            for (size_t j = i; j < n; ++j) acc[j] = (init ? 0.0f : acc[j]) + (float)src[j];
+        }
+    }
+}
+
+hipError_t launch_accumulate_bf16(float* acc, const void* src, size_t n, int init, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(accumulate_bf16_kernel, dim3(grid_for(n / 8 + 1)), dim3(256), 0, stream, acc, (const __bf16*)src, n, init);
+    return hipGetLastError();
+}
+
 }  // namespace fa2

@@ -344,4 +344,128 @@ int ring_attention_forward(const float* Q_local, float* K_local, float* V_local,
     return st2;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Ring backward (past the reference, whose ring is forward-only: SURVEY 8f rank 2).  Q, dO, O, L stay
+// put; the K/V shards are fetched from their owners as in the mesh forward.  While owner o's shard is
+// resident a rank runs the ordinary two backward kernels on (its rows) x (o's keys): the dQ part is
+// added to its own fp32 running sum, the dK/dV parts -- gradients of o's keys -- are sent to o, which adds
+// what it receives to ITS fp32 running sums (send to rank - s, receive from rank + s: a permutation per
+// step).  L must be the log-sum-exp over the WHOLE sequence (the ring forward's output), which is what
+// makes the per-shard pieces add up.  First version: transfers and kernels of a step run one after the
+// other (only the initial K/V fetch overlaps compute).
+namespace {
+struct BwdPlan {
+    size_t shard, acc;                 // bytes of one bf16 shard / of one fp32 running sum
+    size_t off_kv, off_ws, off_tmp, off_rcv, off_acc, total, ws_bytes;
+};
+BwdPlan make_bwd_plan(int B, int H, int nl, int d, int P)
+{
+    BwdPlan p{};
+    const size_t elems = (size_t)B * H * nl * d;
+    p.shard = align256(elems * 2);
+    p.acc = align256(elems * 4);
+    p.ws_bytes = align256(fa2_backward_workspace_bytes(B, H, nl, d, FA2_DTYPE_BF16));
+    size_t off = 0;
+    p.off_kv = off;  off += (size_t)(P > 1 ? P - 1 : 0) * 2 * p.shard;     // fetched K/V shards
+    p.off_ws = off;  off += p.ws_bytes;                                    // the backward kernels' own scratch
+    p.off_tmp = off; off += 3 * p.shard;                                   // this step's dQ, dK, dV (bf16)
+    p.off_rcv = off; off += 2 * p.shard;                                   // received dK, dV contributions
+    p.off_acc = off; off += 3 * p.acc;                                     // fp32 running sums
+    p.total = off;
+    return p;
+}
+}  // namespace
+
+size_t fa2_ring_backward_workspace_bytes(int B, int H, int local_seq_len, int head_dim, int dtype, int nranks)
+{
+    if (B <= 0 || H <= 0 || local_seq_len <= 0 || head_dim <= 0 || nranks <= 0 || dtype != FA2_DTYPE_BF16) return 0;
+    return make_bwd_plan(B, H, local_seq_len, head_dim, nranks).total;
+}
+
+int fa2_ring_attention_backward(fa2_ring_ctx* c,
+                                const void* Q_local, const void* K_local, const void* V_local,
+                                const void* O_local, const float* L_local, const void* dO_local,
+                                void* dQ_local, void* dK_local, void* dV_local,
+                                int B, int H, int total_seq_len, int local_seq_len, int head_dim,
+                                float softmax_scale, int dtype,
+                                void* workspace, size_t workspace_bytes, void* stream_)
+{
+    if (!c || !Q_local || !K_local || !V_local || !O_local || !L_local || !dO_local || !dQ_local || !dK_local || !dV_local)
+        return FA2_ERR_NULL_POINTER;
+    if (B <= 0 || H <= 0 || local_seq_len <= 0 || head_dim <= 0) return FA2_ERR_INVALID_SHAPE;
+    const int P = c->nranks, rank = c->rank;
+    if ((long long)local_seq_len * P != (long long)total_seq_len) return FA2_ERR_INVALID_SHAPE;
+    if (dtype != FA2_DTYPE_BF16) return FA2_ERR_UNSUPPORTED_DTYPE;
+    const BwdPlan pl = make_bwd_plan(B, H, local_seq_len, head_dim, P);
+    if (!workspace || workspace_bytes < pl.total) return FA2_ERR_WORKSPACE;
+
+    hipStream_t stream = (hipStream_t)stream_;
+    char* ws = (char*)workspace;
+    auto slotK = [&](int i) { return (void*)(ws + pl.off_kv + (size_t)i * 2 * pl.shard); };
+    auto slotV = [&](int i) { return (void*)(ws + pl.off_kv + (size_t)i * 2 * pl.shard + pl.shard); };
+    void* bws = ws + pl.off_ws;
+    void* tq = ws + pl.off_tmp; void* tk = ws + pl.off_tmp + pl.shard; void* tv = ws + pl.off_tmp + 2 * pl.shard;
+    void* rk = ws + pl.off_rcv; void* rv = ws + pl.off_rcv + pl.shard;
+    float* aq = (float*)(ws + pl.off_acc); float* ak = (float*)(ws + pl.off_acc + pl.acc); float* av = (float*)(ws + pl.off_acc + 2 * pl.acc);
+    const size_t elems = (size_t)B * H * local_seq_len * head_dim;
+    const size_t bytes = elems * 2;
+
+    // K/V shards from their owners (two grouped exchanges, as in the mesh forward)
+    if (P > 1) {
+        RING_HIP(hipEventRecord(c->ev_in, stream));
+        RING_HIP(hipStreamWaitEvent(c->comm_stream, c->ev_in, 0));
+        for (int part = 0; part < 2; ++part) {
+            const int lo = part == 0 ? 1 : 2, hi = part == 0 ? 1 : P - 1;
+            if (lo > hi) continue;
+            RING_NCCL(ncclGroupStart());
+            int st = FA2_OK;
+            for (int s = lo; s <= hi && !st; ++s)
+                st = exchange_pair(c, K_local, V_local, slotK(s - 1), slotV(s - 1), bytes, (rank + s) % P, (rank - s + P) % P,
+                                   c->comm_stream);
+            ncclResult_t r = ncclGroupEnd();
+            if (st) return st;
+            RING_NCCL(r);
+            RING_HIP(hipEventRecord(c->ev_recv[part], c->comm_stream));
+        }
+    }
+    // D = rowsum(dO o O) and the row constants, once: they depend on local rows only
+    int st = fa2_backward_phases(Q_local, K_local, V_local, O_local, L_local, dO_local, tq, tk, tv, B, H, local_seq_len, head_dim,
+                                 softmax_scale, dtype, 0, bws, pl.ws_bytes, stream, 1);
+    if (st) return st;
+    for (int s = 0; s < P; ++s) {
+        const void* Kc = s == 0 ? K_local : slotK(s - 1);
+        const void* Vc = s == 0 ? V_local : slotV(s - 1);
+        if (s == 1) RING_HIP(hipStreamWaitEvent(stream, c->ev_recv[0], 0));
+        if (s == 2) RING_HIP(hipStreamWaitEvent(stream, c->ev_recv[1], 0));
+        st = fa2_backward_phases(Q_local, Kc, Vc, O_local, L_local, dO_local, tq, tk, tv, B, H, local_seq_len, head_dim,
+                                 softmax_scale, dtype, 0, bws, pl.ws_bytes, stream, 6);
+        if (st) return st;
+        st = fa2_accumulate_bf16(aq, tq, elems, s == 0, stream);
+        if (st) return st;
+        if (s == 0) {                               // own keys: the contribution stays here
+            st = fa2_accumulate_bf16(ak, tk, elems, 1, stream);
+            if (!st) st = fa2_accumulate_bf16(av, tv, elems, 1, stream);
+            if (st) return st;
+            continue;
+        }
+        // gradients of owner (rank - s)'s keys go to it; those of mine computed by rank + s come in
+        RING_HIP(hipEventRecord(c->ev_comp[s], stream));
+        RING_HIP(hipStreamWaitEvent(c->comm_stream, c->ev_comp[s], 0));
+        RING_NCCL(ncclGroupStart());
+        st = exchange_pair(c, tk, tv, rk, rv, bytes, (rank - s + P) % P, (rank + s) % P, c->comm_stream);
+        ncclResult_t r = ncclGroupEnd();
+        if (st) return st;
+        RING_NCCL(r);
+        RING_HIP(hipEventRecord(c->ev_in, c->comm_stream));
+        RING_HIP(hipStreamWaitEvent(stream, c->ev_in, 0));
+        st = fa2_accumulate_bf16(ak, rk, elems, 0, stream);
+        if (!st) st = fa2_accumulate_bf16(av, rv, elems, 0, stream);
+        if (st) return st;
+    }
+    st = fa2_convert_f32_to_bf16(aq, dQ_local, elems, stream);
+    if (!st) st = fa2_convert_f32_to_bf16(ak, dK_local, elems, stream);
+    if (!st) st = fa2_convert_f32_to_bf16(av, dV_local, elems, stream);
+    return st;
+}
+
 }  // extern "C"

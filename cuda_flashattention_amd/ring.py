@@ -40,6 +40,8 @@ RING_SIGNATURES = {
     "fa2_ring_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "fa2_ring_attention_forward": (_i, [_vp] * 6 + [_i, _i, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp]),
     "fa2_ring_attention_forward_causal": (_i, [_vp] * 6 + [_i, _i, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp]),
+    "fa2_ring_backward_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "fa2_ring_attention_backward": (_i, [_vp] * 10 + [_i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
     "ring_attention_forward": (_i, [_vp] * 5 + [_i, _i, _i, _f, _vp, _i, _i]),
     "fa2_ring_exchange_kv": (_i, [_vp] * 5 + [_sz, _vp]),
 }
@@ -151,6 +153,26 @@ def ring_attention_forward(ctx, Q_local, K_local, V_local, softmax_scale=None, s
         ws.data_ptr(), ws.numel(), s.cuda_stream)
     check(st, "fa2_ring_attention_forward")
     return O_local, L_local
+
+
+def ring_attention_backward(ctx, Q_local, K_local, V_local, O_local, L_local, dO_local, softmax_scale=None, stream=None):
+    """dQ, dK, dV for this rank's rows / keys (fa2_ring_attention_backward): O_local, L_local are the ring
+    forward's outputs.  bf16 [B,H,N/P,d], non-causal."""
+    B, H, n, d = Q_local.shape
+    scale = float(softmax_scale) if softmax_scale is not None else 1.0 / math.sqrt(d)
+    code = _dtype_code(Q_local)
+    lib = ring_lib()
+    need = lib.fa2_ring_backward_workspace_bytes(B, H, n, d, code, ctx.nranks)
+    if getattr(ctx, "_bws", None) is None or ctx._bws.numel() < need:
+        ctx._bws = torch.empty(max(need, 256), dtype=torch.uint8, device=Q_local.device)
+    dQ, dK, dV = torch.empty_like(Q_local), torch.empty_like(K_local), torch.empty_like(V_local)
+    s = stream if stream is not None else torch.cuda.current_stream()
+    st = lib.fa2_ring_attention_backward(ctx._h, Q_local.data_ptr(), K_local.data_ptr(), V_local.data_ptr(),
+                                         O_local.data_ptr(), L_local.data_ptr(), dO_local.data_ptr(), dQ.data_ptr(),
+                                         dK.data_ptr(), dV.data_ptr(), B, H, n * ctx.nranks, n, d, scale, code,
+                                         ctx._bws.data_ptr(), ctx._bws.numel(), s.cuda_stream)
+    check(st, "fa2_ring_attention_backward")
+    return dQ, dK, dV
 
 
 # ------------------------------------------------------------------------------------------
@@ -265,6 +287,56 @@ def ring_attention_forward_causal_p2p(dist, Q_local, K_local, V_local, softmax_s
             cur_k, cur_v = rk, rv
     finalize_fn(O, L, Oacc, M)
     return O, L
+
+
+# ------------------------------------------------------------------------------------------
+# The ring backward over torch.distributed point-to-point ops
+# ------------------------------------------------------------------------------------------
+def _gpu_bwd_block(Q, K, V, O, L, dO, scale):
+    from .ops import flash_attention_2_backward
+    return flash_attention_2_backward(Q, K, V, O, L, dO, scale)
+
+
+def ring_attention_backward_p2p(dist, Q_local, K_local, V_local, O_local, L_local, dO_local, softmax_scale=None,
+                                block_fn=None, group=None):
+    """fa2_ring_attention_backward's data flow over torch.distributed P2P ops: the K/V shards relay around the
+    ring; block_fn(Q, K, V, O, L, dO, scale) -> (dQ, dK, dV) is the ordinary backward of the local rows against
+    the resident shard (L: log-sum-exp over the whole sequence); dQ adds up locally, dK/dV go to the shard's
+    owner (send to rank - step, receive from rank + step).  Sums are kept in fp32."""
+    rank, P = dist.get_rank(group), dist.get_world_size(group)
+    d = Q_local.shape[-1]
+    scale = float(softmax_scale) if softmax_scale is not None else 1.0 / math.sqrt(d)
+    block_fn = block_fn or _gpu_bwd_block
+    g = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
+    nxt, prv = g((rank + 1) % P), g((rank - 1 + P) % P)
+    cur_k, cur_v = K_local, V_local
+    spare = [(torch.empty_like(K_local), torch.empty_like(V_local)) for _ in range(min(2, P - 1))]
+    aq = ak = av = None
+    for step in range(P):
+        reqs = []
+        if step < P - 1:
+            rk, rv = spare[step % len(spare)]
+            ops = [dist.P2POp(dist.isend, cur_k, nxt, group), dist.P2POp(dist.irecv, rk, prv, group),
+                   dist.P2POp(dist.isend, cur_v, nxt, group), dist.P2POp(dist.irecv, rv, prv, group)]
+            reqs = dist.batch_isend_irecv(ops)
+        dq, dk, dv = block_fn(Q_local, cur_k, cur_v, O_local, L_local, dO_local, scale)
+        aq = dq.float() if aq is None else aq + dq.float()
+        if step == 0:
+            ak, av = dk.float(), dv.float()
+        else:
+            to, frm = g((rank - step + P) % P), g((rank + step) % P)
+            gk, gv = torch.empty_like(dk), torch.empty_like(dv)
+            dk, dv = dk.contiguous(), dv.contiguous()
+            for r in dist.batch_isend_irecv([dist.P2POp(dist.isend, dk, to, group), dist.P2POp(dist.irecv, gk, frm, group),
+                                             dist.P2POp(dist.isend, dv, to, group), dist.P2POp(dist.irecv, gv, frm, group)]):
+                r.wait()
+            ak += gk.float()
+            av += gv.float()
+        for r in reqs:
+            r.wait()
+        if step < P - 1:
+            cur_k, cur_v = rk, rv
+    return aq.to(Q_local.dtype), ak.to(K_local.dtype), av.to(V_local.dtype)
 
 
 # ------------------------------------------------------------------------------------------

@@ -142,6 +142,10 @@ int fa2_forward_step_strided(const void* Q, const void* K, const void* V,
 int fa2_forward_state_finalize(void* O, float* L, const float* Oacc, const float* M,
                                size_t rows, int head_dim, int dtype, void* stream);
 
+/* acc[i] = (init ? 0 : acc[i]) + src[i] for n bf16 values: fp32 running sums of bf16 contributions (the
+ * ring backward adds each step's gradients this way). */
+int fa2_accumulate_bf16(float* acc, const void* src, size_t n, int init, void* stream);
+
 /* Element-wise helpers (grid-stride, HBM-bound). */
 int fa2_fill_f32(float* dst, size_t n, float value, void* stream);      /* init_array, cuda_helper.h:60-65 */
 int fa2_convert_f32_to_bf16(const float* src, void* dst, size_t n, void* stream);

@@ -85,6 +85,20 @@ int fa2_ring_attention_forward_causal(fa2_ring_ctx* ctx,
                                       float softmax_scale, int dtype, int schedule,
                                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* Ring backward -- past the reference, whose ring is forward-only.  All tensors
+ * [B][H][local_seq_len][d] bf16 (L fp32); O_local / L_local are the ring forward's outputs, L being the
+ * log-sum-exp over the WHOLE sequence.  Each rank runs the ordinary backward kernels on its rows against
+ * every shard of keys: dQ adds up locally, the dK/dV pieces are sent to the shard's owner, all sums in fp32.
+ * Non-causal, bf16 only.  Workspace: fa2_ring_backward_workspace_bytes. */
+size_t fa2_ring_backward_workspace_bytes(int B, int H, int local_seq_len, int head_dim, int dtype, int nranks);
+int fa2_ring_attention_backward(fa2_ring_ctx* ctx,
+                                const void* Q_local, const void* K_local, const void* V_local,
+                                const void* O_local, const float* L_local, const void* dO_local,
+                                void* dQ_local, void* dK_local, void* dV_local,
+                                int B, int H, int total_seq_len, int local_seq_len, int head_dim,
+                                float softmax_scale, int dtype,
+                                void* workspace, size_t workspace_bytes, void* stream);
+
 /* Reference-signature drop-in (ring_attention_kernel.cu:143-156): single head, fp32, `comm` is the
  * caller's ncclComm_t.  Allocates its scratch per call as the reference does, synchronises the
  * device before returning, and -- unlike the reference -- leaves K_local / V_local intact. */

@@ -126,3 +126,53 @@ def test_causal_ring_one_rank_is_local_causal():
             ring.ring_attention_forward(ctx, Q.float(), K.float(), V.float(), causal=True)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("P,B,H,N,d", [(2, 1, 2, 512, 128), (4, 1, 3, 1024, 64)])
+def test_ring_backward_blocks_on_one_gpu(P, B, H, N, d):
+    """The ring backward's per-rank work for P virtual ranks played one after the other on this GPU: the ordinary
+    backward kernels on (local rows) x (one shard of keys) with the WHOLE sequence's L, dQ summed per rank and
+    dK/dV per owner in fp32 -- against the single-GPU backward."""
+    import cuda_flashattention_amd as fa
+    g = torch.Generator().manual_seed(7)
+    mk = lambda s: ((torch.rand(B, H, N, d, generator=g) - 0.5) * s).bfloat16().cuda()
+    Q, K, V, dO = mk(1), mk(1), mk(1), mk(0.4)
+    s = 1.0 / d ** 0.5
+    O, L = fa.flash_attention_2_forward(Q, K, V, s)
+    ref = fa.flash_attention_2_backward(Q, K, V, O, L, dO, s)
+    n = N // P
+    sh = lambda t, r: t[:, :, r * n:(r + 1) * n].contiguous()
+    aq = [None] * P
+    ak = [torch.zeros(B, H, n, d, device="cuda") for _ in range(P)]
+    av = [torch.zeros(B, H, n, d, device="cuda") for _ in range(P)]
+    for r in range(P):
+        for o in range(P):
+            dq, dk, dv = fa.flash_attention_2_backward(sh(Q, r), sh(K, o), sh(V, o), sh(O, r), L[:, :, r * n:(r + 1) * n].contiguous(),
+                                                       sh(dO, r), s)
+            aq[r] = dq.float() if aq[r] is None else aq[r] + dq.float()
+            ak[o] += dk.float()
+            av[o] += dv.float()
+    torch.cuda.synchronize()
+    got = [torch.cat(x, dim=2) for x in (aq, ak, av)]
+    for a, b in zip(got, ref):
+        a, b = a.cpu().numpy(), b.float().cpu().numpy()
+        assert np.linalg.norm(a - b) / np.linalg.norm(b) <= 5e-3
+
+
+def test_ring_backward_one_rank_native():
+    import cuda_flashattention_amd as fa
+    from cuda_flashattention_amd import ring
+    B, H, N, d = 1, 4, 512, 128
+    g = torch.Generator().manual_seed(8)
+    mk = lambda s: ((torch.rand(B, H, N, d, generator=g) - 0.5) * s).bfloat16().cuda()
+    Q, K, V, dO = mk(1), mk(1), mk(1), mk(0.4)
+    ctx = ring.RingContext(None, 0, 1)
+    try:
+        O, L = ring.ring_attention_forward(ctx, Q, K, V)
+        dQ, dK, dV = ring.ring_attention_backward(ctx, Q, K, V, O, L, dO)
+        ref = fa.flash_attention_2_backward(Q, K, V, O, L, dO)
+        torch.cuda.synchronize()
+        for a, b in zip((dQ, dK, dV), ref):
+            assert torch.equal(a, b)              # one rank: bf16 -> fp32 -> bf16 of the same kernels' outputs
+    finally:
+        ctx.close()

@@ -184,3 +184,56 @@ def test_zigzag_helpers():
             assert kinds.count("first_keys") == r and kinds.count("second_rows") == P - 1 - r
     with pytest.raises(ValueError):
         ring.zigzag_rows(100, 0, 3)
+
+
+# ----------------------------------------------------------------------------- ring backward
+def _numpy_bwd_block(Q, K, V, O, L, dO, scale):
+    """block_fn for ring_attention_backward_p2p on CPU fp32 tensors [n, d]: the local rows' gradient pieces against
+    one shard of keys, given the log-sum-exp L of the WHOLE sequence (flash_attention_backward_kernel.cu:47-246
+    restricted to a key range): P = exp(S - L), dP = dO V^T, dS = P (dP - D), D = rowsum(dO O)."""
+    q, k, v, o, l, g = (t.numpy().astype(np.float64) for t in (Q, K, V, O, L, dO))
+    p = np.exp(scale * q @ k.T - l[:, None])
+    ds = p * (g @ v.T - (g * o).sum(1)[:, None])
+    f = lambda a: torch.from_numpy(a.astype(np.float32))
+    return f(scale * ds @ k), f(scale * ds.T @ q), f(p.T @ g)
+
+
+def _bwd_worker(rank, world, port, N, d, scale, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle
+        from cuda_flashattention_amd import ring
+        rng = np.random.default_rng(2)
+        Q, K, V, dO = (rng.uniform(-0.5, 0.5, (N, d)).astype(np.float32) for _ in range(4))
+        O, L = oracle.attention_forward(Q, K, V, float(scale))          # the ring forward's outputs, whole sequence
+        lo, hi = ring.shard_rows(N, rank, world)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float32)[lo:hi]))
+        dQ, dK, dV = ring.ring_attention_backward_p2p(dist, t(Q), t(K), t(V), t(O), t(L), t(dO), scale,
+                                                      block_fn=_numpy_bwd_block)
+        for name, x in (("dQ", dQ), ("dK", dK), ("dV", dV)):
+            parts = [torch.empty_like(x) for _ in range(world)]
+            dist.all_gather(parts, x)
+            if rank == 0:
+                ret[name] = torch.cat(parts).numpy()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,N,d", [(2, 128, 32), (3, 96, 16)])
+def test_ring_backward_matches_one_shot(world, N, d):
+    """Ring backward (past the reference): per-shard gradient pieces, dQ summed locally and dK/dV summed at the
+    shard's owner, equal the one-shot backward over the whole sequence (the oracle's restatement of
+    naive_attention_backward, util/naive_attention.h:84-161)."""
+    import oracle
+    scale = 1.0 / np.sqrt(d)
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_bwd_worker, args=(world, _free_port(), N, d, scale, ret), nprocs=world, join=True)
+        got = {k: ret[k] for k in ("dQ", "dK", "dV")}
+    rng = np.random.default_rng(2)
+    Q, K, V, dO = (rng.uniform(-0.5, 0.5, (N, d)).astype(np.float32) for _ in range(4))
+    dQ, dK, dV = oracle.attention_backward(Q, K, V, dO, float(scale))
+    for name, ref in (("dQ", dQ), ("dK", dK), ("dV", dV)):
+        assert np.abs(got[name] - np.asarray(ref)).max() < 5e-6, name
