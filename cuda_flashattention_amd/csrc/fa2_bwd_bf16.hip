@@ -211,9 +211,6 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dq_kernel(BwdArgs p)
             for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
                 for (int r = r0; r < r0 + n; ++r) {
-#ifdef FA2_ABL_NOVALU
-                    continue;
-#endif
                     float pr = __builtin_amdgcn_exp2f(sacc[qb][kb][r] * c2 - Lq[qb]);
                     if constexpr (MASKED) {
                         const int key = key0 + 32 * kb + acc_row(r, h);
@@ -244,12 +241,10 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dq_kernel(BwdArgs p)
             constexpr int i = decltype(I)::value;
             constexpr int kb = i / KS, sidx = i % KS;
             bf16x8 kn = kb1, vn = vb1;
-#ifndef FA2_ABL_NOLDS
             if constexpr (i + 2 < 2 * KS) {
                 kn = kfrag(std::integral_constant<int, i + 2>{});
                 vn = vfrag(std::integral_constant<int, i + 2>{});
             }
-#endif
             if constexpr (sidx == 0)
                 mfma4_bagpr_init<A_QF + (0 * KS + sidx) * 4, A_QF + (1 * KS + sidx) * 4, A_GF + (0 * KS + sidx) * 4,
                                  A_GF + (1 * KS + sidx) * 4>(sacc[0][kb], sacc[1][kb], dpacc[0][kb], dpacc[1][kb], ka, va,
@@ -294,11 +289,7 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dq_kernel(BwdArgs p)
             constexpr int g = decltype(G)::value;
             constexpr int kb = g / (2 * DT), dt = (g % (2 * DT)) >> 1, sp = g & 1;
             bf16x4 tn0 = tb0, tn1 = tb1;
-#ifdef FA2_ABL_NOLDS
-            if constexpr (false) {
-#else
             if constexpr (g + 2 < 4 * DT) {
-#endif
                 tfrag(std::integral_constant<int, g + 2>{}, tn0, tn1);
                 lds_tr_wait2<4>(ta0, ta1);          // groups g+1 and g+2 may still be in flight
             } else if constexpr (g + 1 < 4 * DT) {
