@@ -325,3 +325,30 @@ def test_forward_backward_capture_into_hip_graph():
     torch.cuda.synchronize()
     for a, b in zip(ref, (O2, L2, dQ2, dK2, dV2)):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype,N,causal,gate", [
+    ("bf16", 65536, False, BF16_REL),      # the ring config's whole sequence on one GPU (BASELINE configs[3] at P = 1)
+    ("bf16", 65536, True, BF16_REL),
+    ("fp8", 32768, True, 5e-2),            # BASELINE configs[4] row length
+])
+def test_long_sequences_sampled_rows(dtype, N, causal, gate):
+    """Maximum sizes: one head pair at the longest sequences BASELINE names, a strided sample of query rows
+    against the oracle (a full pass would be hours of CPU), plus finiteness of everything."""
+    fa, oracle = _fa(), _oracle()
+    B, H, d = 1, 2, 128
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(5)
+    td = torch.bfloat16 if dtype == "bf16" else torch.float8_e4m3fn
+    mk = lambda: (torch.rand(B, H, N, d, device=dev, generator=g) - 0.5).to(td)
+    Q, K, V = mk(), mk(), mk()
+    s = 1.0 / d ** 0.5
+    O, L = fa.flash_attention_2_forward(Q, K, V, s, causal=causal)
+    torch.cuda.synchronize()
+    assert torch.isfinite(O.float()).all() and torch.isfinite(L).all()
+    stride, off = N // 64, 37
+    h = 1
+    Or, Lr = oracle.attention_forward(f32(Q[0, h]), f32(K[0, h]), f32(V[0, h]), s, causal=causal, rows=(off, stride))
+    sel = np.arange(off, N, stride)
+    assert rel(f32(O[0, h])[sel], Or[sel]) <= gate
+    assert np.abs(L[0, h].cpu().numpy()[sel] - Lr[sel]).max() <= 1e-4
