@@ -239,8 +239,10 @@ def main():
 
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if hung:
-        sys.stdout.flush()
+    sys.stdout.flush()
+    if hung or (dist is not None and not args.no_ring):
+        # After a ring leg the ranks may disagree on whether it finished (each has its own deadline): no
+        # further collective, every rank simply leaves.  The timed region and its barriers are long past.
         os._exit(0)
     if dist is not None:
         dist.barrier()
