@@ -44,12 +44,16 @@ __global__ void __launch_bounds__(256) fa2_bwd_delta_kernel(const __bf16* __rest
                                                             const __bf16* __restrict__ O,
                                                             const float* __restrict__ L,
                                                             float* __restrict__ Dv, float* __restrict__ RC,
-                                                            size_t rows, float inv_scale)
+                                                            size_t rows, int nq, int q_hs, int q_row0, size_t rc_plane,
+                                                            float inv_scale)
 {
-    const size_t row = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const size_t r = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 4;
     const int sub = threadIdx.x & 15;
+    const size_t head = r / (size_t)nq, i = r % (size_t)nq;
+    const size_t row = head * (size_t)q_hs + i;              // in the tensors (their pointers address row q_row0 of head 0)
+    const size_t prow = row + (size_t)q_row0;                // in the dense workspace planes
     float acc = 0.0f;
-    if (row < rows) {
+    if (r < rows) {
 #pragma unroll
         for (int c = sub * 8; c < D; c += 128) {
             const bf16x8 a = *reinterpret_cast<const bf16x8*>(dO + row * D + c);
@@ -60,10 +64,10 @@ __global__ void __launch_bounds__(256) fa2_bwd_delta_kernel(const __bf16* __rest
     }
 #pragma unroll
     for (int off = 8; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 16);
-    if (row < rows && sub == 0) {
-        Dv[row] = acc;
-        RC[row] = -L[row] * inv_scale;
-        RC[rows + row] = -acc;
+    if (r < rows && sub == 0) {
+        Dv[prow] = acc;
+        RC[prow] = -L[row] * inv_scale;
+        RC[rc_plane + prow] = -acc;
     }
 }
 
@@ -106,23 +110,27 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dq_kernel(BwdArgs p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qi = lane & 31;
     const int h = lane >> 5;
-    const int N = p.N;
+    const int Nq = p.Nq, N = p.Nk;           // N: keys of the block (every key-side bound below)
 
-    const int nrb = (N + kBwdRows - 1) / kBwdRows;
+    const int nrb = (Nq + kBwdRows - 1) / kBwdRows;
     int head, rb;
     map_block(blockIdx.x, p.BH, nrb, head, rb);
     if (CAUSAL) rb = nrb - 1 - rb;
 
-    const size_t slab = (size_t)head * N * ROWB;
+    const size_t slab = (size_t)head * p.q_hs * ROWB;          // Q, dO, dQ
+    const size_t kslab = (size_t)head * p.k_hs * ROWB;         // K, V
     const char* Qh = (const char*)p.Q + slab;
-    const char* Kh = (const char*)p.K + slab;
-    const char* Vh = (const char*)p.V + slab;
+    const char* Kh = (const char*)p.K + kslab;
+    const char* Vh = (const char*)p.V + kslab;
     const char* Gh = (const char*)p.dO + slab;
 
     const int q0 = rb * kBwdRows + wave * 64;
 
     int ntiles = (N + kDqKV - 1) / kDqKV;
-    if (CAUSAL) ntiles = min(ntiles, min(rb * kBwdRows + kBwdRows - 1, N - 1) / kDqKV + 1);
+    if (CAUSAL) {
+        const int last_key = min(rb * kBwdRows + kBwdRows - 1, Nq - 1) + p.causal_shift;     // last visible key
+        ntiles = min(ntiles, last_key < 0 ? 0 : last_key / kDqKV + 1);
+    }
     const int tend = (ntiles + 1) & ~1;       // whole pairs; a padding tile is fully masked
 
     // ---- resident operands -> AGPRs; per-row constants
@@ -131,7 +139,7 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dq_kernel(BwdArgs p)
     static_for<2>([&](auto QB) {
         constexpr int qb = decltype(QB)::value;
         qrow[qb] = q0 + 32 * qb + qi;
-        const int qld = qrow[qb] < N ? qrow[qb] : N - 1;
+        const int qld = qrow[qb] < Nq ? qrow[qb] : Nq - 1;
         static_for<KS>([&](auto S) {
             constexpr int sidx = decltype(S)::value;
             acc_write_frag<A_QF + (qb * KS + sidx) * 4>(
@@ -140,8 +148,8 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dq_kernel(BwdArgs p)
                 *reinterpret_cast<const bf16x8*>(Gh + (size_t)qld * ROWB + 16 * (2 * sidx + h)));
         });
         static_for<16 * DT>([&](auto R) { acc_write<A_DQ + qb * DT * 16 + decltype(R)::value>(0.0f); });
-        Lq[qb] = p.L[(size_t)head * N + qld] * kLog2e;
-        Dq[qb] = p.D[(size_t)head * N + qld];
+        Lq[qb] = p.L[(size_t)head * p.q_hs + qld] * kLog2e;
+        Dq[qb] = p.D[(size_t)head * p.q_hs + p.q_row0 + qld];
     });
     const float c2 = p.scale * kLog2e;
     // -D of the lane's query row as a whole accumulator tile: the dP^T chains start from it, so
@@ -215,7 +223,7 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dq_kernel(BwdArgs p)
                     if constexpr (MASKED) {
                         const int key = key0 + 32 * kb + acc_row(r, h);
                         bool dead = key >= N;
-                        if (CAUSAL) dead = dead || key > qrow[qb];
+                        if (CAUSAL) dead = dead || key > qrow[qb] + p.causal_shift;
                         if (dead) pr = 0.0f;
                     }
                     dpacc[qb][kb][r] = pr * dpacc[qb][kb][r];     // dP' already has -D in it
@@ -332,7 +340,7 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dq_kernel(BwdArgs p)
     auto tile = [&](auto BUF, int t) {
         const int key0 = t * kDqKV;
         bool masked = key0 + kDqKV > N;
-        if (CAUSAL) masked = masked || key0 + kDqKV - 1 > q0;
+        if (CAUSAL) masked = masked || key0 + kDqKV - 1 > q0 + p.causal_shift;
         if (masked) tile_body(BUF, std::true_type{}, t);
         else tile_body(BUF, std::false_type{}, t);
     };
@@ -359,7 +367,7 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dq_kernel(BwdArgs p)
             bf16x4 o;
             o[0] = (__bf16)(acc_read<R>() * p.scale); o[1] = (__bf16)(acc_read<R + 1>() * p.scale);
             o[2] = (__bf16)(acc_read<R + 2>() * p.scale); o[3] = (__bf16)(acc_read<R + 3>() * p.scale);
-            if (qrow[qb] < N)
+            if (qrow[qb] < Nq)
                 *reinterpret_cast<bf16x4*>((char*)p.dQ + slab + (size_t)qrow[qb] * ROWB + 2 * (32 * dt + 8 * g + 4 * h)) = o;
         });
     });
@@ -403,18 +411,19 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dkdv_kernel(BwdArgs p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ki = lane & 31;
     const int h = lane >> 5;
-    const int N = p.N;
+    const int N = p.Nk, Nq = p.Nq;          // N: keys of the block
 
     const int ncb = (N + kDkKeys - 1) / kDkKeys;
     int head, cb;
     map_block(blockIdx.x, p.BH, ncb, head, cb);     // causal: key block 0 is the heaviest, already first
 
-    const size_t slab = (size_t)head * N * ROWB;
-    const char* Qh = (const char*)p.Q + slab;
+    const size_t slab = (size_t)head * p.k_hs * ROWB;          // K, V, dK, dV
+    const size_t qslab = (size_t)head * p.q_hs * ROWB;         // Q, dO
+    const char* Qh = (const char*)p.Q + qslab;
     const char* Kh = (const char*)p.K + slab;
     const char* Vh = (const char*)p.V + slab;
-    const char* Gh = (const char*)p.dO + slab;
-    const size_t rc_plane = (size_t)p.BH * N;
+    const char* Gh = (const char*)p.dO + qslab;
+    const size_t rc_plane = (size_t)p.BH * p.q_hs;
 
     const int kw0 = cb * kDkKeys + wave * 64;       // first key of this wave
 
@@ -448,9 +457,9 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dkdv_kernel(BwdArgs p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { dkacc[kb][dt][r] = 0.0f; dvacc[kb][dt][r] = 0.0f; }
 
-    const int ntiles = (N + TROWS - 1) / TROWS;
+    const int ntiles = (Nq + TROWS - 1) / TROWS;
     int t0 = 0;
-    if (CAUSAL) t0 = (cb * kDkKeys) / TROWS;        // earlier query rows see none of these keys
+    if (CAUSAL) t0 = min(ntiles, max(0, cb * kDkKeys - p.causal_shift) / TROWS);      // earlier query rows see none of these keys
     // Always whole pairs of tiles (the loop is unrolled by two and must not branch around the
     // second tile: a branch there makes hipcc shuttle the AGPR-pinned accumulators through
     // copies).  An odd count is padded with one tile past the sequence end: all rows masked.
@@ -471,10 +480,10 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dkdv_kernel(BwdArgs p)
     const int dslot = lane % CPR;
     const int prow = wave * RPI + drow;                                   // row inside the tile (first piece)
     const int doff = drow * ROWB + 16 * ((lds_off<D>(prow, dslot) - ROWB * prow) >> 4);
-    const auto q_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Qh, 0, N * ROWB, 0x00020000);
-    const auto g_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Gh, 0, N * ROWB, 0x00020000);
+    const auto q_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Qh, 0, Nq * ROWB, 0x00020000);
+    const auto g_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Gh, 0, Nq * ROWB, 0x00020000);
     const auto rc_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.RC, 0, (int)(2 * rc_plane * 4), 0x00020000);
-    const int rcoff = (int)(((wave == 0 ? 0 : rc_plane) + (size_t)head * N + lane) * 4);
+    const int rcoff = (int)(((wave == 0 ? 0 : rc_plane) + (size_t)head * p.q_hs + p.q_row0 + lane) * 4);
     auto stage = [&](int t, int buf) {
         char* b = bufs + buf * BUFB;
 #pragma unroll
@@ -543,9 +552,9 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dkdv_kernel(BwdArgs p)
         __builtin_amdgcn_sched_barrier(0);
 
         // ---- stage B: dP'[q][key] (dO rows x the V image) beside P = exp2(c S') of the finished S'
-        const bool tail = qb0 + kDkQ > N;
+        const bool tail = qb0 + kDkQ > Nq;
         bool diag = false;
-        if (CAUSAL) diag = qb0 < kw0 + 63;
+        if (CAUSAL) diag = qb0 < kw0 + 63 - p.causal_shift;
         constexpr int RPB = 16 / KS;              // S' registers per key block exponentiated beside one k-step
         bf16x8 ga = lds_read_frag(Gt, roff[0]);
         bf16x8 v0 = lds_read_frag(Vw, roff[0]), v1 = lds_read_frag(Vw, roff[0] + 32 * ROWB);
@@ -571,10 +580,10 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dkdv_kernel(BwdArgs p)
         });
         thread4(sacc[0], sacc[1], dpacc[0], dpacc[1]);
         if (tail || diag) {          // wave-uniform and rare: a branch, not 64 selects per tile
-            const int hi = N - qb0 - 4 * h;
+            const int hi = Nq - qb0 - 4 * h;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
-                const int lo = CAUSAL ? (kw0 + 32 * kb + ki) - qb0 - 4 * h : -1;
+                const int lo = CAUSAL ? (kw0 + 32 * kb + ki) - p.causal_shift - qb0 - 4 * h : -1;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int rr = (r & 3) + 8 * (r >> 2);
@@ -689,15 +698,16 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dkdv_kernel(BwdArgs p)
 template <int D, bool CAUSAL>
 static hipError_t launch_bwd_one(const BwdArgs& a, hipStream_t stream)
 {
-    const size_t rows = (size_t)a.BH * a.N;
+    const size_t rows = (size_t)a.BH * a.Nq;
     hipError_t e = hipSuccess;
     if (a.phases & 1) {
         hipLaunchKernelGGL((fa2_bwd_delta_kernel<D>), dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0,
-                           stream, (const __bf16*)a.dO, (const __bf16*)a.O, a.L, a.D, a.RC, rows, 1.0f / a.scale);
+                           stream, (const __bf16*)a.dO, (const __bf16*)a.O, a.L, a.D, a.RC, rows, a.Nq, a.q_hs, a.q_row0,
+                           (size_t)a.BH * a.q_hs, 1.0f / a.scale);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    const int nb = (a.N + kBwdRows - 1) / kBwdRows;
+    const int nb = (a.Nq + kBwdRows - 1) / kBwdRows;
     constexpr int lds_dq = 2 * 2 * kDqKV * D * 2;
     constexpr int lds_dk = kDkKeys * D * 2 + 2 * (2 * 2 * kDkQ * D * 2 + 512);
     static bool set_dq[64] = {}, set_dk[64] = {};
@@ -711,7 +721,7 @@ static hipError_t launch_bwd_one(const BwdArgs& a, hipStream_t stream)
         if (e != hipSuccess) return e;
     }
     if (a.phases & 4) {
-        const int ncb = (a.N + kDkKeys - 1) / kDkKeys;
+        const int ncb = (a.Nk + kDkKeys - 1) / kDkKeys;
         hipLaunchKernelGGL((fa2_bwd_dkdv_kernel<D, CAUSAL>), dim3((unsigned)(ncb * a.BH)), dim3(256), lds_dk, stream, a);
         e = hipGetLastError();
     }

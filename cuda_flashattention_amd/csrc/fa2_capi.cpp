@@ -12,11 +12,17 @@ namespace {
 
 inline int hip_status(hipError_t e) { return e == hipSuccess ? FA2_OK : FA2_ERR_HIP_BASE - (int)e; }
 
+// The kernels address one head slab through a buffer resource (32-bit byte count, 32-bit byte offsets) and
+// the backward's row-constant planes through another: a slab of N rows must stay below 2 GiB (at 4 bytes per
+// element, the widest type) and the two planes of B H N floats as well.  Larger problems get a status, not a
+// silent wrap-around.
 inline int check_common(int B, int H, int N, int d, float scale)
 {
     if (B <= 0 || H <= 0 || N <= 0 || d <= 0) return FA2_ERR_INVALID_SHAPE;
     if (!(scale > 0.0f)) return FA2_ERR_INVALID_SHAPE;
     if ((long long)B * H > 0x7fffffffLL / 64) return FA2_ERR_INVALID_SHAPE;
+    if ((long long)N * d * 4 > 0x7fffffffLL) return FA2_ERR_INVALID_SHAPE;
+    if ((long long)B * H * N * 8 > 0x7fffffffLL) return FA2_ERR_INVALID_SHAPE;
     return FA2_OK;
 }
 
@@ -63,7 +69,15 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 extern "C" {
 
-const char* fa2_version(void) { return "fa2_mi355x 0.1 (gfx950)"; }
+// The compiler that produced the code objects is part of the version: the kernels pin registers and count
+// wait states by hand, and tests/test_isa_guard.py re-checks the generated code whenever this string changes.
+#define FA2_STR2(x) #x
+#define FA2_STR(x) FA2_STR2(x)
+const char* fa2_version(void)
+{
+    return "fa2_mi355x 0.2 (gfx950; hip " FA2_STR(HIP_VERSION_MAJOR) "." FA2_STR(HIP_VERSION_MINOR) "." FA2_STR(HIP_VERSION_PATCH)
+           "; clang " __clang_version__ ")";
+}
 
 const char* fa2_status_string(int s)
 {
@@ -169,20 +183,41 @@ int fa2_backward_phases(const void* Q, const void* K, const void* V, const void*
     if (st) return st;
     if (!workspace || workspace_bytes < fa2_backward_workspace_bytes(B, H, seq_len, head_dim, dtype))
         return FA2_ERR_WORKSPACE;
-    if (dtype == FA2_DTYPE_BF16) {
-        fa2::BwdArgs a{};
-        a.Q = Q; a.K = K; a.V = V; a.O = O; a.dO = dO; a.L = L; a.dQ = dQ; a.dK = dK; a.dV = dV;
-        a.D = (float*)workspace; a.BH = B * H; a.N = seq_len; a.d = head_dim;
-        a.RC = (float*)((char*)workspace + align256((size_t)B * H * seq_len * sizeof(float)));
-        a.scale = softmax_scale; a.causal = causal ? 1 : 0; a.phases = phases & 7;
-        return hip_status(fa2::launch_bwd_bf16(a, (hipStream_t)stream));
-    }
+    if (dtype == FA2_DTYPE_BF16)
+        return fa2_backward_block(Q, K, V, O, L, dO, dQ, dK, dV, B, H, seq_len, seq_len, head_dim, softmax_scale, dtype, 0, 0, 0,
+                                  causal, 0, workspace, workspace_bytes, stream, phases);
     fa2::F32Args a{};
     a.Q = (const float*)Q; a.K = (const float*)K; a.V = (const float*)V; a.O = (float*)O;
     a.L = (float*)L; a.dO = (const float*)dO; a.dQ = (float*)dQ; a.dK = (float*)dK; a.dV = (float*)dV;
     a.D = (float*)workspace; a.BH = B * H; a.N = seq_len; a.d = head_dim;
     a.scale = softmax_scale; a.causal = causal ? 1 : 0; a.phases = phases & 7;
     return hip_status(fa2::launch_bwd_f32(a, (hipStream_t)stream));
+}
+
+int fa2_backward_block(const void* Q, const void* K, const void* V, const void* O, const float* L,
+                       const void* dO, void* dQ, void* dK, void* dV,
+                       int B, int H, int q_len, int kv_len, int head_dim, float softmax_scale, int dtype,
+                       int q_head_stride, int kv_head_stride, int q_row0, int causal, int causal_shift,
+                       void* workspace, size_t workspace_bytes, void* stream, int phases)
+{
+    if (!Q || !K || !V || !O || !L || !dO || !dQ || !dK || !dV) return FA2_ERR_NULL_POINTER;
+    const int q_hs = q_head_stride ? q_head_stride : q_len, k_hs = kv_head_stride ? kv_head_stride : kv_len;
+    int st = check_common(B, H, q_len, head_dim, softmax_scale);
+    if (!st) st = check_common(B, H, kv_len > 0 ? kv_len : 1, head_dim, softmax_scale);
+    if (!st) st = check_common(B, H, q_hs > 0 ? q_hs : 1, head_dim, softmax_scale);
+    if (st) return st;
+    if (kv_len <= 0 || q_row0 < 0 || q_hs < q_row0 + q_len || k_hs < kv_len) return FA2_ERR_INVALID_SHAPE;
+    if (dtype != FA2_DTYPE_BF16) return FA2_ERR_UNSUPPORTED_DTYPE;
+    st = check_dim(head_dim, dtype);
+    if (st) return st;
+    if (!workspace || workspace_bytes < fa2_backward_workspace_bytes(B, H, q_hs, head_dim, dtype)) return FA2_ERR_WORKSPACE;
+    fa2::BwdArgs a{};
+    a.Q = Q; a.K = K; a.V = V; a.O = O; a.dO = dO; a.L = L; a.dQ = dQ; a.dK = dK; a.dV = dV;
+    a.D = (float*)workspace; a.BH = B * H; a.Nq = q_len; a.Nk = kv_len; a.d = head_dim;
+    a.RC = (float*)((char*)workspace + align256((size_t)B * H * q_hs * sizeof(float)));
+    a.q_hs = q_hs; a.k_hs = k_hs; a.q_row0 = q_row0;
+    a.scale = softmax_scale; a.causal = causal ? 1 : 0; a.causal_shift = causal ? causal_shift : 0; a.phases = phases & 7;
+    return hip_status(fa2::launch_bwd_bf16(a, (hipStream_t)stream));
 }
 
 int fa2_forward_step(const void* Q, const void* K, const void* V,
@@ -269,8 +304,14 @@ int flash_attention_2_backward(const float* Q, const float* K, const float* V,
 
 int fa2_accumulate_bf16(float* acc, const void* src, size_t n, int init, void* stream)
 {
+    return fa2_accumulate_bf16_2d(acc, src, 1, n, n, init, stream);
+}
+
+int fa2_accumulate_bf16_2d(float* acc, const void* src, size_t rows, size_t cols, size_t pitch, int init, void* stream)
+{
     if (!acc || !src) return FA2_ERR_NULL_POINTER;
-    return hip_status(fa2::launch_accumulate_bf16(acc, src, n, init, (hipStream_t)stream));
+    if (pitch < cols && rows > 1) return FA2_ERR_INVALID_SHAPE;
+    return hip_status(fa2::launch_accumulate_bf16(acc, src, rows, cols, pitch, init, (hipStream_t)stream));
 }
 
 int fa2_fill_f32(float* dst, size_t n, float value, void* stream)

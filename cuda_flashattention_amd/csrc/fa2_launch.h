@@ -29,8 +29,8 @@ struct FwdArgs {
 };
 
 hipError_t launch_fwd_bf16(const FwdArgs& a, hipStream_t stream);
-// acc (fp32) = (init) or += src (bf16), n elements.
-hipError_t launch_accumulate_bf16(float* acc, const void* src, size_t n, int init, hipStream_t stream);
+// acc (fp32) = (init) or += src (bf16): `rows` runs of `cols` elements, `pitch` elements apart in both.
+hipError_t launch_accumulate_bf16(float* acc, const void* src, size_t rows, size_t cols, size_t pitch, int init, hipStream_t stream);
 // Ring epilogue: O = bf16(Oacc / l), L = m + ln l for `rows` consecutive rows (l arrives in L).
 hipError_t launch_finalize_state(const float* Oacc, const float* M, float* L, void* O, size_t rows, int d, hipStream_t stream);
 
@@ -49,13 +49,16 @@ hipError_t launch_fwd_fp8(const FwdFp8Args& a, hipStream_t stream);
 
 struct BwdArgs {
     const void* Q; const void* K; const void* V; const void* O; const void* dO;  // bf16
-    const float* L;   // [BH][N] natural-log LSE from the forward
+    const float* L;   // [BH][q_hs] natural-log LSE over ALL keys of the row (pointer at row q_row0 of head 0, like Q)
     void* dQ; void* dK; void* dV;   // bf16
-    float* D;         // [BH][N] workspace: rowsum(dO o O)
-    float* RC;        // [2][BH][N] workspace: -L/scale and -D, the row constants of the dK/dV kernel
-    int BH, N, d;
+    float* D;         // [BH][q_hs] workspace plane: rowsum(dO o O)                (dense, NOT offset by q_row0)
+    float* RC;        // [2][BH][q_hs] workspace planes: -L/scale and -D, the row constants of the dK/dV kernel
+    int BH, Nq, Nk, d;
+    int q_hs, k_hs;   // rows between consecutive heads of Q/O/dO/dQ/L and of K/V/dK/dV (>= Nq, Nk; dense: == Nq, Nk)
+    int q_row0;       // the block's rows are rows [q_row0, q_row0 + Nq) of every head (indexes the workspace planes)
     float scale;
-    int causal;
+    int causal;       // key j is visible to local row i iff j <= i + causal_shift
+    int causal_shift;
     int phases;       // bit 0: D = rowsum(dO o O), bit 1: dQ kernel, bit 2: dK/dV kernel (7 = all)
 };
 

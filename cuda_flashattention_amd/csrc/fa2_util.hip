@@ -112,29 +112,37 @@ hipError_t launch_finalize_state(const float* Oacc, const float* M, float* L, vo
 }
 
 // acc (fp32) = or += src (bf16): the ring backward keeps its running gradients in fp32 and adds each step's
-// bf16 contribution to them.
-__global__ void __launch_bounds__(256) accumulate_bf16_kernel(float* acc, const __bf16* src, size_t n, int init)
+// bf16 contribution to them.  blockIdx.y walks `rows` runs of `cols` elements, `pitch` elements apart.
+__global__ void __launch_bounds__(256) accumulate_bf16_kernel(float* acc, const __bf16* src, size_t rows, size_t cols,
+                                                                size_t pitch, int init)
 {
     const size_t stride = (size_t)gridDim.x * 256 * 8;
-    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += stride) {
-        if (i + 8 <= n) {
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + i);
-            f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
-            if (!init) { a0 = *reinterpret_cast<const f32x4*>(acc + i); a1 = *reinterpret_cast<const f32x4*>(acc + i + 4); }
+    for (size_t row = blockIdx.y; row < rows; row += gridDim.y) {
+        float* a = acc + row * pitch;
+        const __bf16* b = src + row * pitch;
+        for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8; i < cols; i += stride) {
+            if (i + 8 <= cols) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(b + i);
+                f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+                if (!init) { a0 = *reinterpret_cast<const f32x4*>(a + i); a1 = *reinterpret_cast<const f32x4*>(a + i + 4); }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { a0[e] += (float)v[e]; a1[e] += (float)v[4 + e]; }
-            *reinterpret_cast<f32x4*>(acc + i) = a0;
-            *reinterpret_cast<f32x4*>(acc + i + 4) = a1;
-        } else {
-            for (size_t j = i; j < n; ++j) acc[j] = (init ? 0.0f : acc[j]) + (float)src[j];
+                for (int e = 0; e < 4; ++e) { a0[e] += (float)v[e]; a1[e] += (float)v[4 + e]; }
+                *reinterpret_cast<f32x4*>(a + i) = a0;
+                *reinterpret_cast<f32x4*>(a + i + 4) = a1;
+            } else {
+                for (size_t j = i; j < cols; ++j) a[j] = (init ? 0.0f : a[j]) + (float)b[j];
+            }
         }
     }
 }
 
-hipError_t launch_accumulate_bf16(float* acc, const void* src, size_t n, int init, hipStream_t stream)
+hipError_t launch_accumulate_bf16(float* acc, const void* src, size_t rows, size_t cols, size_t pitch, int init, hipStream_t stream)
 {
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(accumulate_bf16_kernel, dim3(grid_for(n / 8 + 1)), dim3(256), 0, stream, acc, (const __bf16*)src, n, init);
+    if (rows == 0 || cols == 0) return hipSuccess;
+    const unsigned gy = (unsigned)(rows < 1024 ? rows : 1024);
+    unsigned gx = grid_for(cols / 8 + 1);
+    if (gy > 1 && gx > 2048 / gy + 1) gx = 2048 / gy + 1;
+    hipLaunchKernelGGL(accumulate_bf16_kernel, dim3(gx, gy), dim3(256), 0, stream, acc, (const __bf16*)src, rows, cols, pitch, init);
     return hipGetLastError();
 }
 

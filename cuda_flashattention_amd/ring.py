@@ -7,13 +7,11 @@ reference's MPI as the *bootstrap* only (it carries the 128-byte RCCL unique id 
 the data path is libfa2_ring_mi355x.so: RCCL send/recv over xGMI on its own stream, event-fenced
 against the FA2 step kernel (include/fa2_ring_mi355x.h).
 
-Two transports share one schedule:
-  * RingContext / ring_attention_forward      -- the native C ABI (RCCL called from C++);
-  * ring_attention_forward_p2p                -- the same relay schedule written over
-    torch.distributed point-to-point ops with a pluggable step function.  With backend "nccl"
-    this is again RCCL over xGMI driving the same HIP step kernel; with "gloo" and a CPU step
-    function supplied by the caller it is how the N > 1 path is exercised without GPUs
-    (tests/test_ring_gloo.py).
+The schedules themselves (relay, mesh, causal zig-zag, backward) live in ONE place,
+csrc/ring/fa2_ring.cpp; this module only marshals tensors into the C ABI.  The library does all
+device work through a backend table (fa2_ring_backend): RCCL + HIP + the kernels in the product,
+and in tests/ a one-GPU loopback transport, a CPU simulator and a gloo transport that run the same
+C++ schedule code at P = 2..8 (tests/test_gpu_ring_loopback.py, test_ring_sim.py, test_ring_gloo.py).
 """
 import ctypes
 import math
@@ -36,12 +34,15 @@ RING_SIGNATURES = {
     "fa2_ring_get_unique_id": (_i, [_vp]),
     "fa2_ring_ctx_create": (_i, [ctypes.POINTER(_vp), _vp, _i, _i]),
     "fa2_ring_ctx_create_from_comm": (_i, [ctypes.POINTER(_vp), _vp, _i, _i]),
+    "fa2_ring_default_backend": (_i, [_vp]),
+    "fa2_ring_ctx_create_with_backend": (_i, [ctypes.POINTER(_vp), _vp, _i, _i]),
     "fa2_ring_ctx_destroy": (_i, [_vp]),
     "fa2_ring_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "fa2_ring_attention_forward": (_i, [_vp] * 6 + [_i, _i, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp]),
     "fa2_ring_attention_forward_causal": (_i, [_vp] * 6 + [_i, _i, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp]),
     "fa2_ring_backward_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "fa2_ring_attention_backward": (_i, [_vp] * 10 + [_i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
+    "fa2_ring_attention_backward_causal": (_i, [_vp] * 10 + [_i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
     "ring_attention_forward": (_i, [_vp] * 5 + [_i, _i, _i, _f, _vp, _i, _i]),
     "fa2_ring_exchange_kv": (_i, [_vp] * 5 + [_sz, _vp]),
 }
@@ -155,9 +156,10 @@ def ring_attention_forward(ctx, Q_local, K_local, V_local, softmax_scale=None, s
     return O_local, L_local
 
 
-def ring_attention_backward(ctx, Q_local, K_local, V_local, O_local, L_local, dO_local, softmax_scale=None, stream=None):
-    """dQ, dK, dV for this rank's rows / keys (fa2_ring_attention_backward): O_local, L_local are the ring
-    forward's outputs.  bf16 [B,H,N/P,d], non-causal."""
+def ring_attention_backward(ctx, Q_local, K_local, V_local, O_local, L_local, dO_local, softmax_scale=None, stream=None,
+                            causal=False):
+    """dQ, dK, dV for this rank's rows / keys (fa2_ring_attention_backward[_causal]): O_local, L_local are the ring
+    forward's outputs.  bf16 [B,H,N/P,d]; causal=True: the zig-zag layout of the causal forward."""
     B, H, n, d = Q_local.shape
     scale = float(softmax_scale) if softmax_scale is not None else 1.0 / math.sqrt(d)
     code = _dtype_code(Q_local)
@@ -167,176 +169,13 @@ def ring_attention_backward(ctx, Q_local, K_local, V_local, O_local, L_local, dO
         ctx._bws = torch.empty(max(need, 256), dtype=torch.uint8, device=Q_local.device)
     dQ, dK, dV = torch.empty_like(Q_local), torch.empty_like(K_local), torch.empty_like(V_local)
     s = stream if stream is not None else torch.cuda.current_stream()
-    st = lib.fa2_ring_attention_backward(ctx._h, Q_local.data_ptr(), K_local.data_ptr(), V_local.data_ptr(),
-                                         O_local.data_ptr(), L_local.data_ptr(), dO_local.data_ptr(), dQ.data_ptr(),
-                                         dK.data_ptr(), dV.data_ptr(), B, H, n * ctx.nranks, n, d, scale, code,
-                                         ctx._bws.data_ptr(), ctx._bws.numel(), s.cuda_stream)
+    fn = lib.fa2_ring_attention_backward_causal if causal else lib.fa2_ring_attention_backward
+    st = fn(ctx._h, Q_local.data_ptr(), K_local.data_ptr(), V_local.data_ptr(),
+            O_local.data_ptr(), L_local.data_ptr(), dO_local.data_ptr(), dQ.data_ptr(),
+            dK.data_ptr(), dV.data_ptr(), B, H, n * ctx.nranks, n, d, scale, code,
+            ctx._bws.data_ptr(), ctx._bws.numel(), s.cuda_stream)
     check(st, "fa2_ring_attention_backward")
     return dQ, dK, dV
-
-
-# ------------------------------------------------------------------------------------------
-# The relay schedule over torch.distributed point-to-point ops
-# ------------------------------------------------------------------------------------------
-def _gpu_step(Q, K, V, O, L, Oacc, M, scale, first, last):
-    from .ops import forward_step
-    forward_step(Q, K, V, O, L, Oacc, M, scale, first, last)
-
-
-def ring_attention_forward_p2p(dist, Q_local, K_local, V_local, softmax_scale=None, step_fn=None,
-                               group=None):
-    """The reference's schedule (ring_attention_kernel.cu:196-231): for step in 0..P-1 compute on
-    the resident K/V shard while it is sent to rank+1 and the next one is received from rank-1
-    (ring_exchange_kv), then swap.  step_fn(Q, K, V, O, L, Oacc, M, scale, first, last) folds one
-    shard into the running state; the default is the HIP step kernel."""
-    rank, P = dist.get_rank(group), dist.get_world_size(group)
-    d = Q_local.shape[-1]
-    scale = float(softmax_scale) if softmax_scale is not None else 1.0 / math.sqrt(d)
-    step_fn = step_fn or _gpu_step
-    O = torch.empty_like(Q_local)
-    L = torch.empty(Q_local.shape[:-1], dtype=torch.float32, device=Q_local.device)
-    M = torch.empty_like(L)
-    Oacc = torch.empty(Q_local.shape, dtype=torch.float32, device=Q_local.device)
-    nxt, prv = (rank + 1) % P, (rank - 1 + P) % P
-    if group is not None:
-        nxt, prv = dist.get_global_rank(group, nxt), dist.get_global_rank(group, prv)
-    cur_k, cur_v = K_local, V_local
-    spare = [(torch.empty_like(K_local), torch.empty_like(V_local)) for _ in range(min(2, P - 1))]
-    for step in range(P):
-        reqs = []
-        if step < P - 1:
-            rk, rv = spare[step % len(spare)]
-            ops = [dist.P2POp(dist.isend, cur_k, nxt, group), dist.P2POp(dist.irecv, rk, prv, group),
-                   dist.P2POp(dist.isend, cur_v, nxt, group), dist.P2POp(dist.irecv, rv, prv, group)]
-            reqs = dist.batch_isend_irecv(ops)
-        step_fn(Q_local, cur_k, cur_v, O, L, Oacc, M, scale, step == 0, step == P - 1)
-        for r in reqs:
-            r.wait()
-        if step < P - 1:
-            cur_k, cur_v = rk, rv
-    return O, L
-
-
-# ------------------------------------------------------------------------------------------
-# The causal zig-zag schedule over torch.distributed point-to-point ops
-# ------------------------------------------------------------------------------------------
-def _gpu_block(Q, K, V, O, L, Oacc, M, scale, kind):
-    """One block of the causal ring on the HIP step kernel (bf16 [B,H,2c,d] tensors):
-    "local": causal over the local rows, starts the state; "first_keys": the first chunk of K/V against every
-    local row; "second_rows": all of K/V against the rows of the second local chunk."""
-    lib = _capi.lib()
-    B, H, n, d = Q.shape
-    c = n // 2
-    s = torch.cuda.current_stream().cuda_stream
-    if kind == "local":
-        st = lib.fa2_forward_step_strided(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), L.data_ptr(),
-                                          Oacc.data_ptr(), M.data_ptr(), B, H, n, n, d, scale, FA2_DTYPE_BF16, 1, 0, 0, 0, 1, 0, s)
-    elif kind == "first_keys":
-        st = lib.fa2_forward_step_strided(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), L.data_ptr(),
-                                          Oacc.data_ptr(), M.data_ptr(), B, H, n, c, d, scale, FA2_DTYPE_BF16, 0, 0, 0, n, 0, 0, s)
-    else:
-        e = c * d
-        st = lib.fa2_forward_step_strided(Q.data_ptr() + 2 * e, K.data_ptr(), V.data_ptr(), O.data_ptr() + 2 * e,
-                                          L.data_ptr() + 4 * c, Oacc.data_ptr() + 4 * e, M.data_ptr() + 4 * c,
-                                          B, H, c, n, d, scale, FA2_DTYPE_BF16, 0, 0, n, 0, 0, 0, s)
-    check(st, "fa2_forward_step_strided")
-
-
-def _gpu_finalize(O, L, Oacc, M):
-    B, H, n, d = O.shape
-    check(_capi.lib().fa2_forward_state_finalize(O.data_ptr(), L.data_ptr(), Oacc.data_ptr(), M.data_ptr(), B * H * n, d,
-                                                 FA2_DTYPE_BF16, torch.cuda.current_stream().cuda_stream),
-          "fa2_forward_state_finalize")
-
-
-def causal_block_kind(rank, owner):
-    """Which block of the zig-zag causal ring rank computes while owner's shard is resident."""
-    return "local" if owner == rank else ("first_keys" if owner < rank else "second_rows")
-
-
-def ring_attention_forward_causal_p2p(dist, Q_local, K_local, V_local, softmax_scale=None, block_fn=None,
-                                      finalize_fn=None, group=None):
-    """fa2_ring_attention_forward_causal's relay schedule over torch.distributed P2P ops (zig-zag sharded
-    local rows, see zigzag_rows).  block_fn(Q, K, V, O, L, Oacc, M, scale, kind) folds one block into the
-    state, finalize_fn(O, L, Oacc, M) turns the state into results; defaults: the HIP kernels."""
-    rank, P = dist.get_rank(group), dist.get_world_size(group)
-    d = Q_local.shape[-1]
-    scale = float(softmax_scale) if softmax_scale is not None else 1.0 / math.sqrt(d)
-    block_fn = block_fn or _gpu_block
-    finalize_fn = finalize_fn or _gpu_finalize
-    O = torch.empty_like(Q_local)
-    L = torch.empty(Q_local.shape[:-1], dtype=torch.float32, device=Q_local.device)
-    M = torch.empty_like(L)
-    Oacc = torch.empty(Q_local.shape, dtype=torch.float32, device=Q_local.device)
-    nxt, prv = (rank + 1) % P, (rank - 1 + P) % P
-    if group is not None:
-        nxt, prv = dist.get_global_rank(group, nxt), dist.get_global_rank(group, prv)
-    cur_k, cur_v = K_local, V_local
-    spare = [(torch.empty_like(K_local), torch.empty_like(V_local)) for _ in range(min(2, P - 1))]
-    for step in range(P):
-        reqs = []
-        if step < P - 1:
-            rk, rv = spare[step % len(spare)]
-            ops = [dist.P2POp(dist.isend, cur_k, nxt, group), dist.P2POp(dist.irecv, rk, prv, group),
-                   dist.P2POp(dist.isend, cur_v, nxt, group), dist.P2POp(dist.irecv, rv, prv, group)]
-            reqs = dist.batch_isend_irecv(ops)
-        block_fn(Q_local, cur_k, cur_v, O, L, Oacc, M, scale, causal_block_kind(rank, kv_owner(rank, step, P)))
-        for r in reqs:
-            r.wait()
-        if step < P - 1:
-            cur_k, cur_v = rk, rv
-    finalize_fn(O, L, Oacc, M)
-    return O, L
-
-
-# ------------------------------------------------------------------------------------------
-# The ring backward over torch.distributed point-to-point ops
-# ------------------------------------------------------------------------------------------
-def _gpu_bwd_block(Q, K, V, O, L, dO, scale):
-    from .ops import flash_attention_2_backward
-    return flash_attention_2_backward(Q, K, V, O, L, dO, scale)
-
-
-def ring_attention_backward_p2p(dist, Q_local, K_local, V_local, O_local, L_local, dO_local, softmax_scale=None,
-                                block_fn=None, group=None):
-    """fa2_ring_attention_backward's data flow over torch.distributed P2P ops: the K/V shards relay around the
-    ring; block_fn(Q, K, V, O, L, dO, scale) -> (dQ, dK, dV) is the ordinary backward of the local rows against
-    the resident shard (L: log-sum-exp over the whole sequence); dQ adds up locally, dK/dV go to the shard's
-    owner (send to rank - step, receive from rank + step).  Sums are kept in fp32."""
-    rank, P = dist.get_rank(group), dist.get_world_size(group)
-    d = Q_local.shape[-1]
-    scale = float(softmax_scale) if softmax_scale is not None else 1.0 / math.sqrt(d)
-    block_fn = block_fn or _gpu_bwd_block
-    g = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
-    nxt, prv = g((rank + 1) % P), g((rank - 1 + P) % P)
-    cur_k, cur_v = K_local, V_local
-    spare = [(torch.empty_like(K_local), torch.empty_like(V_local)) for _ in range(min(2, P - 1))]
-    aq = ak = av = None
-    for step in range(P):
-        reqs = []
-        if step < P - 1:
-            rk, rv = spare[step % len(spare)]
-            ops = [dist.P2POp(dist.isend, cur_k, nxt, group), dist.P2POp(dist.irecv, rk, prv, group),
-                   dist.P2POp(dist.isend, cur_v, nxt, group), dist.P2POp(dist.irecv, rv, prv, group)]
-            reqs = dist.batch_isend_irecv(ops)
-        dq, dk, dv = block_fn(Q_local, cur_k, cur_v, O_local, L_local, dO_local, scale)
-        aq = dq.float() if aq is None else aq + dq.float()
-        if step == 0:
-            ak, av = dk.float(), dv.float()
-        else:
-            to, frm = g((rank - step + P) % P), g((rank + step) % P)
-            gk, gv = torch.empty_like(dk), torch.empty_like(dv)
-            dk, dv = dk.contiguous(), dv.contiguous()
-            for r in dist.batch_isend_irecv([dist.P2POp(dist.isend, dk, to, group), dist.P2POp(dist.irecv, gk, frm, group),
-                                             dist.P2POp(dist.isend, dv, to, group), dist.P2POp(dist.irecv, gv, frm, group)]):
-                r.wait()
-            ak += gk.float()
-            av += gv.float()
-        for r in reqs:
-            r.wait()
-        if step < P - 1:
-            cur_k, cur_v = rk, rv
-    return aq.to(Q_local.dtype), ak.to(K_local.dtype), av.to(V_local.dtype)
 
 
 # ------------------------------------------------------------------------------------------
@@ -376,31 +215,23 @@ def bench_ring(dist, rank, world, steps=3, warmup=1, B=1, H=16, n_local=8192, d=
         return dt / steps
 
     out = {"config": {"workload": f"ring FA2 forward bf16, seq-sharded N={N} (N/P={n_local}), d={d}, B={B}, H={H}",
-                      "n_gpus": world}, "unit": "TFLOP/s"}
+                      "n_gpus": world}, "unit": "TFLOP/s", "transport": "rccl-native (libfa2_ring_mi355x.so)"}
+    # ONE code path: the native library (RCCL called from C++).  A failure is reported as such -- never replaced by
+    # a number from another transport.  Both schedules are listed; `value` is chosen by a FIXED rule, not by speed:
+    # the mesh schedule (owner-direct fetch over the 7 xGMI links, this build's default for P > 2), else the relay.
     results = {}
-    ctx = None
+    ctx = RingContext(dist, rank, world)
     try:
-        ctx = RingContext(dist, rank, world)
         for name in ("relay", "mesh") if world > 1 else ("relay",):
             O = torch.empty_like(Q)
             L = torch.empty(B, H, n_local, dtype=torch.float32, device=dev)
             sec = time_it(lambda: ring_attention_forward(ctx, Q, K, V, scale, schedule=name, O_local=O, L_local=L))
-            results[f"rccl-native/{name}"] = {"ms": round(sec * 1e3, 4), "tflops": round(flops / sec / 1e12, 2)}
-    except Exception as e:   # report, then try the torch.distributed transport
-        results["rccl-native"] = {"error": repr(e)}
-    if world > 1:
-        try:
-            sec = time_it(lambda: ring_attention_forward_p2p(dist, Q, K, V, scale))
-            results["torch.distributed-nccl/relay"] = {"ms": round(sec * 1e3, 4), "tflops": round(flops / sec / 1e12, 2)}
-        except Exception as e:
-            results["torch.distributed-nccl/relay"] = {"error": repr(e)}
-    if ctx is not None:
+            results[name] = {"ms": round(sec * 1e3, 4), "tflops": round(flops / sec / 1e12, 2)}
+    finally:
         ctx.close()
-    ok = {k: v for k, v in results.items() if "tflops" in v}
-    out["transports"] = results
-    if ok:
-        best = max(ok, key=lambda k: ok[k]["tflops"])
-        out["value"] = ok[best]["tflops"]
-        out["best"] = best
-        out["pct_mfma_peak"] = round(100.0 * ok[best]["tflops"] / world / 2516.6, 2)
+    out["schedules"] = results
+    best = "mesh" if world > 2 else "relay"
+    out["value"] = results[best]["tflops"]
+    out["schedule"] = best
+    out["pct_mfma_peak"] = round(100.0 * results[best]["tflops"] / world / 2516.6, 2)
     return out

@@ -113,6 +113,23 @@ int fa2_backward_phases(const void* Q, const void* K, const void* V, const void*
                         int dtype, int causal, void* workspace, size_t workspace_bytes, void* stream,
                         int phases);
 
+/* The backward of a rectangular BLOCK of the score matrix: q_len query rows (a row range of every head,
+ * consecutive heads q_head_stride rows apart in Q / O / dO / dQ / L; 0 = q_len) against kv_len keys (K / V /
+ * dK / dV, heads kv_head_stride rows apart; 0 = kv_len).  dQ = this block's contribution to the rows' dQ,
+ * dK / dV = the rows' contribution to the keys' gradients; L must be the log-sum-exp over ALL keys of the
+ * row (not only this block's), which is what makes blocks add up -- the unit of work of the ring backward.
+ * With causal != 0 key j is visible to local query i iff j <= i + causal_shift.  The workspace is
+ * fa2_backward_workspace_bytes(B, H, q_head_stride ? q_head_stride : q_len, ...): its planes are dense
+ * [B][H][q_head_stride] and the block's rows are rows [q_row0, q_row0 + q_len) of every head (the tensor
+ * pointers address row q_row0 of head 0), so phase bit 0 (D = rowsum(dO o O)) may be run once over the
+ * dense local tensors (q_row0 = 0, q_len = q_head_stride) and reused by every block of them.  bf16 only.
+ * fa2_backward is the block q_len = kv_len = seq_len, strides 0, q_row0 0, shift 0. */
+int fa2_backward_block(const void* Q, const void* K, const void* V, const void* O, const float* L,
+                       const void* dO, void* dQ, void* dK, void* dV,
+                       int B, int H, int q_len, int kv_len, int head_dim, float softmax_scale, int dtype,
+                       int q_head_stride, int kv_head_stride, int q_row0, int causal, int causal_shift,
+                       void* workspace, size_t workspace_bytes, void* stream, int phases);
+
 /* One resumable forward step: folds the kv_len keys/values of a resident shard into the running
  * state of q_len local query rows -- the unit of work of ring_attention_forward_kernel
  * (ring_attention_kernel.cu:13-140).  State between steps: Mrun = running max (natural units),
@@ -145,6 +162,9 @@ int fa2_forward_state_finalize(void* O, float* L, const float* Oacc, const float
 /* acc[i] = (init ? 0 : acc[i]) + src[i] for n bf16 values: fp32 running sums of bf16 contributions (the
  * ring backward adds each step's gradients this way). */
 int fa2_accumulate_bf16(float* acc, const void* src, size_t n, int init, void* stream);
+/* The same over `rows` runs of `cols` contiguous elements that start `pitch` elements apart in both acc and
+ * src (a row range of every head of a [B][H][N][d] tensor). */
+int fa2_accumulate_bf16_2d(float* acc, const void* src, size_t rows, size_t cols, size_t pitch, int init, void* stream);
 
 /* Element-wise helpers (grid-stride, HBM-bound). */
 int fa2_fill_f32(float* dst, size_t n, float value, void* stream);      /* init_array, cuda_helper.h:60-65 */

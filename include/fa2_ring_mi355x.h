@@ -58,6 +58,59 @@ int fa2_ring_ctx_create_from_comm(fa2_ring_ctx** out, void* nccl_comm, int rank,
 
 int fa2_ring_ctx_destroy(fa2_ring_ctx* ctx);
 
+/* ---- backend injection ------------------------------------------------------------------------
+ * Everything the ring schedules do to a device goes through this table: ordering (streams and
+ * events), the grouped point-to-point transport and the per-step compute.  The product table
+ * (fa2_ring_default_backend) is HIP streams/events + RCCL ncclSend/ncclRecv + the kernels of
+ * libfa2_mi355x.so, and that is what fa2_ring_ctx_create / _from_comm install.  A caller may install
+ * another table -- an MPI or in-process transport, or, in tests/, (a) a loopback transport that runs
+ * P ranks as P host threads on ONE GPU (hipMemcpyAsync between the ranks' buffers) and (b) a CPU
+ * simulator that executes the enqueued operations in adversarial legal orders with the oracle's ring
+ * step: both run the SAME relay / mesh / causal / backward schedule code as an 8-GPU RCCL job.
+ * Contract: every callback returns FA2_OK or a negative status, is asynchronous with respect to the
+ * device (nothing in a schedule blocks the host), and `stream` / `event` are whatever stream_create /
+ * event_create produced (the caller's compute stream is passed through untouched).  send/recv are
+ * matched per (source, destination) pair in issue order and complete on `stream`, grouped between
+ * group_start and group_end like ncclGroupStart/ncclGroupEnd (util/nccl_utils.h:117-131). */
+typedef struct fa2_ring_backend {
+    void* user;   /* first argument of every callback */
+    int (*stream_create)(void* user, void** stream_out);
+    int (*stream_destroy)(void* user, void* stream);
+    int (*event_create)(void* user, void** event_out);
+    int (*event_destroy)(void* user, void* event);
+    int (*event_record)(void* user, void* event, void* stream);
+    int (*stream_wait_event)(void* user, void* stream, void* event);
+    int (*group_start)(void* user);
+    int (*send)(void* user, const void* buf, size_t bytes, int peer, void* stream);
+    int (*recv)(void* user, void* buf, size_t bytes, int peer, void* stream);
+    int (*group_end)(void* user);
+    /* fa2_forward_step_strided (bf16) / fa2_forward_step (fp32: strides and causal are 0) */
+    int (*forward_step)(void* user, const void* Q, const void* K, const void* V, void* O, float* L, float* Oacc, float* M,
+                        int B, int H, int q_len, int kv_len, int head_dim, float softmax_scale, int dtype,
+                        int first, int last, int q_head_stride, int kv_head_stride, int causal, int causal_shift,
+                        void* stream);
+    /* fa2_forward_state_finalize */
+    int (*state_finalize)(void* user, void* O, float* L, const float* Oacc, const float* M, size_t rows, int head_dim,
+                          int dtype, void* stream);
+    /* fa2_backward_block */
+    int (*backward_block)(void* user, const void* Q, const void* K, const void* V, const void* O, const float* L,
+                          const void* dO, void* dQ, void* dK, void* dV, int B, int H, int q_len, int kv_len, int head_dim,
+                          float softmax_scale, int dtype, int q_head_stride, int kv_head_stride, int q_row0, int causal,
+                          int causal_shift, void* workspace, size_t workspace_bytes, void* stream, int phases);
+    /* fa2_accumulate_bf16_2d, fa2_convert_f32_to_bf16 */
+    int (*accumulate_bf16_2d)(void* user, float* acc, const void* src, size_t rows, size_t cols, size_t pitch, int init,
+                              void* stream);
+    int (*convert_f32_to_bf16)(void* user, const float* src, void* dst, size_t n, void* stream);
+} fa2_ring_backend;
+
+/* Fills *out with the product table.  Its transport entries need a context with an RCCL communicator
+ * as `user` (fa2_ring_ctx_create sets that); the ordering and compute entries ignore `user`. */
+int fa2_ring_default_backend(fa2_ring_backend* out);
+
+/* A context on the CURRENT device that runs the schedules over *backend (copied).  No RCCL
+ * communicator is created; rank / nranks are the caller's. */
+int fa2_ring_ctx_create_with_backend(fa2_ring_ctx** out, const fa2_ring_backend* backend, int rank, int nranks);
+
 /* Bytes of workspace fa2_ring_attention_forward needs per rank. */
 size_t fa2_ring_workspace_bytes(int B, int H, int local_seq_len, int head_dim, int dtype,
                                 int nranks, int schedule);
@@ -89,7 +142,9 @@ int fa2_ring_attention_forward_causal(fa2_ring_ctx* ctx,
  * [B][H][local_seq_len][d] bf16 (L fp32); O_local / L_local are the ring forward's outputs, L being the
  * log-sum-exp over the WHOLE sequence.  Each rank runs the ordinary backward kernels on its rows against
  * every shard of keys: dQ adds up locally, the dK/dV pieces are sent to the shard's owner, all sums in fp32.
- * Non-causal, bf16 only.  Workspace: fa2_ring_backward_workspace_bytes. */
+ * The gradient pieces of a step travel while the next step's kernels run (two sets of buffers, event-fenced).
+ * bf16 only.  Workspace: fa2_ring_backward_workspace_bytes.  fa2_ring_attention_backward_causal is the
+ * backward of fa2_ring_attention_forward_causal (same zig-zag layout of the local rows). */
 size_t fa2_ring_backward_workspace_bytes(int B, int H, int local_seq_len, int head_dim, int dtype, int nranks);
 int fa2_ring_attention_backward(fa2_ring_ctx* ctx,
                                 const void* Q_local, const void* K_local, const void* V_local,
@@ -98,6 +153,13 @@ int fa2_ring_attention_backward(fa2_ring_ctx* ctx,
                                 int B, int H, int total_seq_len, int local_seq_len, int head_dim,
                                 float softmax_scale, int dtype,
                                 void* workspace, size_t workspace_bytes, void* stream);
+int fa2_ring_attention_backward_causal(fa2_ring_ctx* ctx,
+                                       const void* Q_local, const void* K_local, const void* V_local,
+                                       const void* O_local, const float* L_local, const void* dO_local,
+                                       void* dQ_local, void* dK_local, void* dV_local,
+                                       int B, int H, int total_seq_len, int local_seq_len, int head_dim,
+                                       float softmax_scale, int dtype,
+                                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* Reference-signature drop-in (ring_attention_kernel.cu:143-156): single head, fp32, `comm` is the
  * caller's ncclComm_t.  Allocates its scratch per call as the reference does, synchronises the

@@ -1,0 +1,248 @@
+"""CPU: the C++ ring schedules of libfa2_ring_mi355x.so (csrc/ring/fa2_ring.cpp) executed at P = 2, 3, 4, 8 by the
+discrete-event simulator of tests/ring_sim.py -- the relay and mesh forward, the causal zig-zag forward and the
+ring backward (plain and causal), each under several adversarial execution orders, against one-shot attention
+from the oracle on the gathered sequence (what 04_ring_attention.cu:103-142 does with MPI_Gather +
+compare_outputs).  What runs is the shipped schedule code: slot rotation, event fences and peer arithmetic;
+only streams, transport and the per-step arithmetic are the simulator's."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import ring_sim as rs
+from ring_sim import FA2_DTYPE_BF16, FA2_DTYPE_F32, MESH, RELAY, SimWorld
+
+
+def _inputs(B, H, N, d, seed, bf16):
+    rng = np.random.default_rng(seed)
+    Q, K, V = (rng.uniform(-0.5, 0.5, (B, H, N, d)).astype(np.float32) for _ in range(3))
+    dO = rng.uniform(-0.2, 0.2, (B, H, N, d)).astype(np.float32)
+    if bf16:
+        Q, K, V, dO = (rs.round_bf16(a).reshape(B, H, N, d) for a in (Q, K, V, dO))
+    return Q, K, V, dO
+
+
+def _store(a, bf16):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return rs.f32_to_bf16(a).reshape(a.shape) if bf16 else a.copy()
+
+
+def _load(a, bf16):
+    return rs.bf16_to_f32(a).reshape(a.shape) if bf16 else a
+
+
+def _poison(nbytes):
+    return np.full(max(nbytes, 256), 0xFF, dtype=np.uint8)      # NaNs to whoever reads before writing
+
+
+def _late(world, stream, *arrays):
+    """The caller's inputs are PRODUCED by earlier work on its stream (as a projection kernel would): the arrays hold
+    poison until an operation queued ahead of the ring call fills them in.  A schedule whose comm stream does not
+    wait for the caller's stream ships the poison."""
+    for a in arrays:
+        good = a.copy()
+        a[...] = 0xFFFF if a.dtype == np.uint16 else np.nan
+        world.streams[stream]["ops"].append(("compute", lambda a=a, good=good: a.__setitem__(Ellipsis, good), "produce"))
+
+
+def _rows_of(rank, P, N, causal):
+    return rs.zigzag_rows(N, rank, P) if causal else list(range(rank * (N // P), (rank + 1) * (N // P)))
+
+
+def run_forward(P, B, H, N, d, dtype, schedule, causal, seed, policy):
+    lib = rs.ring_lib()
+    bf16 = dtype == FA2_DTYPE_BF16
+    Q, K, V, _ = _inputs(B, H, N, d, 100 + seed, bf16)
+    scale = 1.0 / np.sqrt(d)
+    world = SimWorld(P, seed, policy)
+    n = N // P
+    ranks = []
+    for r in range(P):
+        rows = _rows_of(r, P, N, causal)
+        q, k, v = (_store(a[:, :, rows], bf16) for a in (Q, K, V))
+        o = np.full((B, H, n, d), 0xFFFF if bf16 else np.nan, dtype=np.uint16 if bf16 else np.float32)
+        l = np.full((B, H, n), np.nan, dtype=np.float32)
+        need = lib.fa2_ring_workspace_bytes(B, H, n, d, dtype, P, schedule)
+        ws = _poison(need)
+        ctx = world.ctx(r)
+        stream = world.new_stream(r)
+        _late(world, stream, k, v)
+        fn = lib.fa2_ring_attention_forward_causal if causal else lib.fa2_ring_attention_forward
+        st = fn(ctx, q.ctypes.data, k.ctypes.data, v.ctypes.data, o.ctypes.data, l.ctypes.data, B, H, N, n, d, scale, dtype,
+                schedule, ws.ctypes.data, need, stream)
+        assert st == 0 and not world.errors, (st, world.errors)
+        ranks.append(dict(rows=rows, q=q, k=k, v=v, o=o, l=l, ws=ws, ctx=ctx))
+    world.run()
+    for rk in ranks:
+        rk["k0"], rk["v0"] = _store(K[:, :, rk["rows"]], bf16), _store(V[:, :, rk["rows"]], bf16)
+    assert not world.errors, world.errors
+    O = np.empty((B, H, N, d), np.float32)
+    L = np.empty((B, H, N), np.float32)
+    for rk in ranks:
+        assert np.array_equal(rk["k"], rk["k0"]) and np.array_equal(rk["v"], rk["v0"])      # caller's shards preserved
+        O[:, :, rk["rows"]] = _load(rk["o"], bf16)
+        L[:, :, rk["rows"]] = rk["l"]
+        assert lib.fa2_ring_ctx_destroy(rk["ctx"]) == 0
+    return (Q, K, V, scale), O, L
+
+
+def _check_forward(inp, O, L, causal, bf16):
+    import oracle
+    Q, K, V, scale = inp
+    Or, Lr = oracle.attention_forward(Q, K, V, float(scale), causal=causal)
+    if bf16:      # the state is fp32; O is rounded to bf16 once at the end
+        assert np.linalg.norm(O - Or) / np.linalg.norm(Or) < 3e-3
+        assert np.abs(L - Lr).max() < 1e-5
+    else:         # 04_ring_attention.cu:134-135 asks rtol 5e-3 / atol 1.0; fp32 state does far better
+        assert np.abs(O - Or).max() < 2e-6
+        assert np.abs(L - Lr).max() < 2e-6
+
+
+@pytest.mark.parametrize("schedule", [RELAY, MESH], ids=["relay", "mesh"])
+@pytest.mark.parametrize("P", [2, 3, 4, 8])
+def test_forward_f32_every_policy(P, schedule):
+    """fp32 (the reference's type), every scheduling policy: must match the oracle whatever the order."""
+    for i, policy in enumerate(rs.POLICIES):
+        inp, O, L = run_forward(P, 1, 2, 24 * P, 16, FA2_DTYPE_F32, schedule, False, i, policy)
+        _check_forward(inp, O, L, False, False)
+
+
+@pytest.mark.parametrize("schedule", [RELAY, MESH], ids=["relay", "mesh"])
+@pytest.mark.parametrize("P", [2, 4, 8])
+def test_forward_bf16_random_orders(P, schedule):
+    for seed in range(4):
+        inp, O, L = run_forward(P, 2, 1, 16 * P, 64, FA2_DTYPE_BF16, schedule, False, seed, "random")
+        _check_forward(inp, O, L, False, True)
+
+
+@pytest.mark.parametrize("schedule", [RELAY, MESH], ids=["relay", "mesh"])
+@pytest.mark.parametrize("P", [2, 3, 4, 8])
+def test_forward_causal_zigzag(P, schedule):
+    for i, policy in enumerate(rs.POLICIES):
+        inp, O, L = run_forward(P, 1, 2, 16 * P, 64, FA2_DTYPE_BF16, schedule, True, i, policy)
+        _check_forward(inp, O, L, True, True)
+
+
+def test_reference_ring_pattern_two_ranks():
+    """The reference's own ring test data (create_simple_test_data, scale 1) at a reduced length (N = 512 instead
+    of 5096 to stay in CPU seconds), P = 2 as run.sh:2, judged with its criterion (04_ring_attention.cu:134-135)."""
+    from oracle import recipes
+    lib = rs.ring_lib()
+    N, d, P = 512, 64, 2
+    Q, K, V = recipes.ring_pattern(N, d)
+    world = SimWorld(P, 0, "random")
+    outs = []
+    for r in range(P):
+        lo, hi = r * N // P, (r + 1) * N // P
+        q, k, v = (np.ascontiguousarray(a[lo:hi], dtype=np.float32) for a in (Q, K, V))
+        o = np.full((N // P, d), np.nan, np.float32)
+        l = np.full(N // P, np.nan, np.float32)
+        need = lib.fa2_ring_workspace_bytes(1, 1, N // P, d, FA2_DTYPE_F32, P, RELAY)
+        ws = _poison(need)
+        st = lib.fa2_ring_attention_forward(world.ctx(r), q.ctypes.data, k.ctypes.data, v.ctypes.data, o.ctypes.data,
+                                            l.ctypes.data, 1, 1, N, N // P, d, 1.0, FA2_DTYPE_F32, RELAY, ws.ctypes.data, need,
+                                            world.new_stream(r))
+        assert st == 0
+        outs.append((q, k, v, o, l, ws))
+    world.run()
+    O = np.concatenate([t[3] for t in outs])
+    assert recipes.compare_outputs(recipes.ring_pattern_expected(N, d), O, rtol=5e-3, atol=1.0) == 0
+
+
+def run_backward(P, B, H, N, d, causal, seed, policy):
+    import oracle
+    lib = rs.ring_lib()
+    Q, K, V, dO = _inputs(B, H, N, d, 200 + seed, True)
+    scale = 1.0 / np.sqrt(d)
+    Of, Lf = oracle.attention_forward(Q, K, V, float(scale), causal=causal)
+    Of = rs.round_bf16(Of).reshape(Of.shape)               # the forward hands O over in bf16
+    world = SimWorld(P, seed, policy)
+    n = N // P
+    ranks = []
+    for r in range(P):
+        rows = _rows_of(r, P, N, causal)
+        q, k, v, o, g = (_store(a[:, :, rows], True) for a in (Q, K, V, Of, dO))
+        l = np.ascontiguousarray(Lf[:, :, rows], dtype=np.float32)
+        outs = [np.full((B, H, n, d), 0xFFFF, dtype=np.uint16) for _ in range(3)]
+        need = lib.fa2_ring_backward_workspace_bytes(B, H, n, d, FA2_DTYPE_BF16, P)
+        ws = _poison(need)
+        ctx = world.ctx(r)
+        stream = world.new_stream(r)
+        _late(world, stream, k, v)
+        fn = lib.fa2_ring_attention_backward_causal if causal else lib.fa2_ring_attention_backward
+        st = fn(ctx, q.ctypes.data, k.ctypes.data, v.ctypes.data, o.ctypes.data, l.ctypes.data, g.ctypes.data,
+                outs[0].ctypes.data, outs[1].ctypes.data, outs[2].ctypes.data, B, H, N, n, d, scale, FA2_DTYPE_BF16,
+                ws.ctypes.data, need, stream)
+        assert st == 0 and not world.errors, (st, world.errors)
+        ranks.append(dict(rows=rows, keep=(q, k, v, o, g, l, ws), outs=outs, ctx=ctx))
+    world.run()
+    assert not world.errors, world.errors
+    got = [np.empty((B, H, N, d), np.float32) for _ in range(3)]
+    for rk in ranks:
+        for t in range(3):
+            got[t][:, :, rk["rows"]] = _load(rk["outs"][t], True)
+        assert lib.fa2_ring_ctx_destroy(rk["ctx"]) == 0
+    ref = oracle.attention_backward(Q, K, V, dO, float(scale), causal=causal)
+    return got, ref
+
+
+@pytest.mark.parametrize("causal", [False, True], ids=["plain", "causal"])
+@pytest.mark.parametrize("P", [2, 3, 4, 8])
+def test_backward_every_policy(P, causal):
+    """dQ, dK, dV of the whole sequence from P ranks' pieces.  Each piece is rounded to bf16 before it is added
+    (as the kernels produce them), the sums are fp32: rel-L2 <= 5e-3 (DESIGN.md, bf16 gate)."""
+    for i, policy in enumerate(rs.POLICIES):
+        got, ref = run_backward(P, 1, 2, 16 * P, 32, causal, i, policy)
+        for a, b, name in zip(got, ref, ("dQ", "dK", "dV")):
+            assert np.isfinite(a).all(), name
+            assert np.linalg.norm(a - b) / np.linalg.norm(b) < 5e-3, (name, policy)
+
+
+def test_exchange_kv_is_a_ring_shift():
+    """fa2_ring_exchange_kv (ring_exchange_kv, nccl_utils.h:133-142): every rank receives its predecessor's buffers."""
+    lib = rs.ring_lib()
+    P, nbytes = 4, 1000
+    world = SimWorld(P, 3, "random")
+    bufs = []
+    for r in range(P):
+        sk = np.full(nbytes, r + 1, np.uint8)
+        sv = np.full(nbytes, 101 + r, np.uint8)
+        rk, rv = np.zeros(nbytes, np.uint8), np.zeros(nbytes, np.uint8)
+        assert lib.fa2_ring_exchange_kv(world.ctx(r), sk.ctypes.data, rk.ctypes.data, sv.ctypes.data, rv.ctypes.data, nbytes,
+                                        world.new_stream(r)) == 0
+        bufs.append((sk, sv, rk, rv))
+    world.run()
+    for r in range(P):
+        prev = (r - 1) % P
+        assert (bufs[r][2] == prev + 1).all() and (bufs[r][3] == 101 + prev).all()
+
+
+def test_simulator_sees_a_missing_fence():
+    """The simulator's own sanity: a consumer on another stream WITHOUT an event fence must observe stale data under
+    some order, and never with the fence -- otherwise a green schedule test would prove nothing."""
+    def trial(fenced, seed):
+        w = SimWorld(1, seed, "random")
+        be = w.backend(0)
+        a, b = w.new_stream(0), w.new_stream(0, "comm")
+        box = {"x": 0, "seen": None}
+        ev = ctypes.c_void_p()
+        be.event_create(None, ctypes.byref(ev))
+        w.streams[a]["ops"].append(("compute", lambda: box.__setitem__("x", 1), "produce"))
+        be.event_record(None, ev, a)
+        if fenced:
+            be.stream_wait_event(None, b, ev)
+        w.streams[b]["ops"].append(("compute", lambda: box.__setitem__("seen", box["x"]), "consume"))
+        w.run()
+        return box["seen"]
+    assert all(trial(True, s) == 1 for s in range(20))
+    assert any(trial(False, s) == 0 for s in range(20))
+
+
+def test_unmatched_exchange_is_reported_as_deadlock():
+    lib = rs.ring_lib()
+    world = SimWorld(2, 0, "random")
+    a = np.zeros(64, np.uint8)
+    assert lib.fa2_ring_exchange_kv(world.ctx(0), a.ctypes.data, a.ctypes.data, a.ctypes.data, a.ctypes.data, 64,
+                                    world.new_stream(0)) == 0
+    with pytest.raises(rs.Deadlock):          # rank 1 never posts its side
+        world.run()
