@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(256) fa2_bwd_delta_kernel(const __bf16* __rest
 constexpr int kBwdRows = 256;   // query rows per workgroup (kernel 1)
 constexpr int kDqWaves = 4;
 constexpr int kDqKV = 64;       // keys per streamed tile in kernel 1
-constexpr int kDkQ = 32;        // query rows per streamed tile in kernel 2
+constexpr int kDkQ = 32;        // query rows per sub-tile in kernel 2
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -374,37 +374,79 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dq_kernel(BwdArgs p)
 }
 
 // --------------------------------------------------------------------------- kernel 2: dK, dV
-// Workgroup = 4 waves = 256 keys of one head, ONE wave per SIMD so that each wave may use the
-// whole 512-entry register file: a wave owns 64 keys (two 32-key blocks) and keeps dK^T and dV^T
-// of those keys -- 2 x 2 x (D/32) accumulator tiles = 256 registers at D = 128, pinned to AGPRs
-// (mfma32_acc) -- plus its K fragments resident in VGPRs.  V of the workgroup's 256 keys sits in
-// LDS (read once per tile as the B operand of dP); Q/dO tiles of 32 query rows stream through a
-// double-buffered LDS image and every row/transposed fragment read from it feeds BOTH key
-// blocks.  At one wave per SIMD nothing hides a stall, so:
-//   * tiles arrive by LDS-DMA (global_load_lds, 16 B per lane, source address pre-swizzled so the
-//     linear LDS write produces the swizzled image): no staging registers, no ds_write, and the
-//     only vector-memory waits in the loop are the ones in front of the per-tile barrier;
-//   * the row constants come pre-transformed from kernel 0 and are DMA'd too;
-//   * fragment reads are software-pipelined one k-step ahead of the MFMAs that use them;
-//   * the tile loop is unrolled by two so every LDS address is a loop-invariant register plus
-//     an immediate.
+// Workgroup = 4 waves = 256 keys of one head, ONE wave per SIMD so that each wave may use the whole 512-entry
+// register file: a wave owns 64 keys (two 32-key blocks) and keeps dK^T and dV^T of those keys -- 2 x 2 x (D/32)
+// accumulator tiles = 256 registers at D = 128 -- plus its K fragments resident in VGPRs.  V of the workgroup's 256
+// keys sits in LDS (read as the B operand of dP); Q/dO tiles of 64 query rows stream through a double-buffered LDS
+// image by LDS-DMA (source address pre-swizzled so the linear LDS write produces the swizzled image), the row
+// constants (pre-transformed by kernel 0) with them.
+//
+// The main loop is NOT scheduled by hipcc.  The kernel is compiled with amdgpu_num_vgpr(60): hipcc may allocate
+// v0..v59 only (loop control, DMA issue, the epilogue's temporaries, the loop-invariant LDS addresses it passes
+// in as operands); v60..v255 and the whole accumulator file are named by the generated bodies of
+// fa2_bwd_dkdv_body.inc (tools/gen_dkdv_body.py: register map, stage order, per-gap issue budget).  One body =
+// one 32-row sub-tile = 4 KS + 8 DT MFMAs with every LDS read, wait, exponential, product and pack assigned to
+// an MFMA gap; bodies chain cyclically (each ends with the first reads of the next), so the matrix pipe does
+// not drain at sub-tile or tile seams.  Two barriers per 64-row tile: B1 at its start (everyone is done with the
+// previous tile's buffer -> the DMA of the next tile may overwrite it) and B2 inside the body of sub-tile 1
+// (vmcnt(0) + barrier: the next tile has landed) in front of its first read of the other buffer.
+// Masking (sequence tail, causal diagonal) is a second body variant that zeroes P behind each exp; dS then uses
+// v_mul_legacy (0 x anything = 0), so rows past the end contribute nothing whatever their row constants hold.
 constexpr int kDkWaves = 4;
 constexpr int kDkKeys = 64 * kDkWaves;      // keys per workgroup
 
+#include "fa2_bwd_dkdv_body.inc"
+
+// One literal VGPR move / accumulator access per call; the clobber of v255 is what makes the kernel descriptor
+// allocate the registers the bodies name (a reserved register to hipcc: it never allocates it).
+template <int R>
+__device__ __forceinline__ void dkdv_vset(uint32_t x)
+{
+    asm volatile("v_mov_b32 v%c1, %0" : : "v"(x), "i"(R) : "v255");
+}
+
+#define FA2_DKDV_CLOBBERS "memory", "vcc", "s10", "s11", "v255", FA2_ACC_CLOBBERS
+
+template <int D, int BUF, int SH, bool MASKED>
+__device__ __forceinline__ void dkdv_body(const uint32_t (&roff)[D / 16], const uint32_t (&toff)[D / 16], uint32_t rc, float c2,
+                                          int hi, int lo0, int lo1)
+{
+#define FA2_DKDV_CASE(DD, B, S, M)                                                                                             \
+    if constexpr (D == DD && BUF == B && SH == S && MASKED == bool(M))                                                           \
+        asm volatile(FA2_DKDV_BODY_D##DD##_B##B##_S##S##_M##M : : FA2_DKDV_OPS_##DD, [rc] "v"(rc), [c2] "s"(c2), [hi] "v"(hi),    \
+                     [lo0] "v"(lo0), [lo1] "v"(lo1) : FA2_DKDV_CLOBBERS);
+    FA2_DKDV_CASE(128, 0, 0, 0) FA2_DKDV_CASE(128, 0, 1, 0) FA2_DKDV_CASE(128, 1, 0, 0) FA2_DKDV_CASE(128, 1, 1, 0)
+    FA2_DKDV_CASE(128, 0, 0, 1) FA2_DKDV_CASE(128, 0, 1, 1) FA2_DKDV_CASE(128, 1, 0, 1) FA2_DKDV_CASE(128, 1, 1, 1)
+    FA2_DKDV_CASE(64, 0, 0, 0) FA2_DKDV_CASE(64, 0, 1, 0) FA2_DKDV_CASE(64, 1, 0, 0) FA2_DKDV_CASE(64, 1, 1, 0)
+    FA2_DKDV_CASE(64, 0, 0, 1) FA2_DKDV_CASE(64, 0, 1, 1) FA2_DKDV_CASE(64, 1, 0, 1) FA2_DKDV_CASE(64, 1, 1, 1)
+#undef FA2_DKDV_CASE
+}
+
+template <int D>
+__device__ __forceinline__ void dkdv_prologue(const uint32_t (&roff)[D / 16], const uint32_t (&toff)[D / 16], uint32_t rc)
+{
+    // the early reads of the first sub-tile (buffer 0, sub-tile 0); the masked and plain variants issue the same ones
+    if constexpr (D == 128) asm volatile(FA2_DKDV_PRO_D128_M0 : : FA2_DKDV_OPS_128, [rc] "v"(rc) : FA2_DKDV_CLOBBERS);
+    else asm volatile(FA2_DKDV_PRO_D64_M0 : : FA2_DKDV_OPS_64, [rc] "v"(rc) : FA2_DKDV_CLOBBERS);
+}
+
 template <int D, bool CAUSAL>
-__global__ void __launch_bounds__(256, 1) fa2_bwd_dkdv_kernel(BwdArgs p)
+__global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(60))) fa2_bwd_dkdv_kernel(BwdArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWB = D * 2;
-    constexpr int TROWS = 2 * kDkQ;             // rows per DMA tile: two 32-row sub-tiles, one barrier
+    constexpr int TROWS = 64;                   // rows per DMA tile: two 32-row sub-tiles
     constexpr int TILEB = TROWS * ROWB;         // Q (or dO) tile
-    constexpr int HALFB = kDkQ * ROWB;          // one sub-tile
     constexpr int BUFB = 2 * TILEB + 512;       // Q tile, dO tile, 64 x (-L/scale), 64 x (-D)
     constexpr int CPR = D / 8;                  // 16-byte chunks per row
     constexpr int RPI = 64 / CPR;               // rows one DMA wave-instruction covers (1 KiB)
     constexpr int NINS = TROWS / RPI;           // DMA instructions per tensor per tile: 16 or 8
     constexpr int KS = D / 16;
     constexpr int DT = D / 32;
+    constexpr int KF = D == 128 ? FA2_DKDV_D128_KF : FA2_DKDV_D64_KF;
+    constexpr int ROFFV = D == 128 ? FA2_DKDV_D128_ROFFV : FA2_DKDV_D64_ROFFV;
+    constexpr int A_DK = D == 128 ? FA2_DKDV_D128_A_DK : FA2_DKDV_D64_A_DK;
+    constexpr int A_DV = D == 128 ? FA2_DKDV_D128_A_DV : FA2_DKDV_D64_A_DV;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -428,18 +470,22 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dkdv_kernel(BwdArgs p)
     const int kw0 = cb * kDkKeys + wave * 64;       // first key of this wave
 
     char* const bufs = smem;                         // [2][Q tile | dO tile | row constants]
-    char* const Vimg = smem + 2 * BUFB;              // after them: every read offset fits a 16-bit immediate
+    char* const Vimg = smem + 2 * BUFB;              // after them: every tile offset fits a 16-bit immediate
 
-    // K fragments of both key blocks: B operands of S = Q K^T (lane = key column).
-    bf16x8 kf[2][KS];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    // K fragments of both key blocks: B operands of S' = Q K^T (lane = key column) -> v[KF ...]
+    static_for<2>([&](auto KB) {
+        constexpr int kb = decltype(KB)::value;
         int kr = kw0 + 32 * kb + ki;
         kr = kr < N ? kr : N - 1;
-#pragma unroll
-        for (int s = 0; s < KS; ++s)
-            kf[kb][s] = *reinterpret_cast<const bf16x8*>(Kh + (size_t)kr * ROWB + 16 * (2 * s + h));
-    }
+        static_for<KS>([&](auto S) {
+            constexpr int sidx = decltype(S)::value;
+            const u32x4 w = *reinterpret_cast<const u32x4*>(Kh + (size_t)kr * ROWB + 16 * (2 * sidx + h));
+            dkdv_vset<KF + 4 * (kb * KS + sidx) + 0>(w[0]);
+            dkdv_vset<KF + 4 * (kb * KS + sidx) + 1>(w[1]);
+            dkdv_vset<KF + 4 * (kb * KS + sidx) + 2>(w[2]);
+            dkdv_vset<KF + 4 * (kb * KS + sidx) + 3>(w[3]);
+        });
+    });
     // V image: the workgroup's 256 keys, swizzled like every other tile.
     for (int c = tid; c < kDkKeys * CPR; c += 256) {
         const int row = c / CPR, ch = c % CPR;
@@ -448,34 +494,26 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dkdv_kernel(BwdArgs p)
         *reinterpret_cast<u32x4*>(Vimg + lds_off<D>(row, ch)) =
             *reinterpret_cast<const u32x4*>(Vh + (size_t)kr * ROWB + 16 * ch);
     }
-
-    f32x16 dkacc[2][DT], dvacc[2][DT];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { dkacc[kb][dt][r] = 0.0f; dvacc[kb][dt][r] = 0.0f; }
+    static_for<32 * DT>([&](auto R) {
+        acc_write<A_DK + decltype(R)::value>(0.0f);
+        acc_write<A_DV + decltype(R)::value>(0.0f);
+    });
 
     const int ntiles = (Nq + TROWS - 1) / TROWS;
     int t0 = 0;
     if (CAUSAL) t0 = min(ntiles, max(0, cb * kDkKeys - p.causal_shift) / TROWS);      // earlier query rows see none of these keys
-    // Always whole pairs of tiles (the loop is unrolled by two and must not branch around the
-    // second tile: a branch there makes hipcc shuttle the AGPR-pinned accumulators through
-    // copies).  An odd count is padded with one tile past the sequence end: all rows masked.
+    // Always whole pairs of tiles (the loop is unrolled by two: every LDS offset is an immediate).  An odd count is
+    // padded with one tile past the sequence end: all of its rows are masked.
     const int tend = t0 + ((ntiles - t0 + 1) & ~1);
 
     const float c2 = p.scale * kLog2e;
 
-    // ---- LDS-DMA staging.  Wave w issues pieces w, w+4, ... of the 2*NINS pieces of a tile; a
-    // piece is RPI rows = 1 KiB written linearly, lane l -> row l / CPR, slot l % CPR; the slot
-    // must hold chunk (slot ^ f(row)), f being lds_off's swizzle: so the SOURCE address is
-    // permuted, the LDS side stays linear (fa2_common.h: lds_off is an involution in ch).
-    // Wave w's pieces are w and w + 4 of Q and of dO: the swizzle term is the same for all of them
-    // (it depends on the row modulo 16 only), so ONE per-lane byte offset (voffset) serves every
-    // DMA of the wave; the tile/piece part of the address is wave-uniform (soffset) and the slab
-    // is described by a buffer resource whose range check turns rows past the end of the
-    // sequence into zeros -- no clamping arithmetic, no 64-bit per-lane pointers.
+    // ---- LDS-DMA staging.  Wave w issues pieces w, w+4, ... of the 2*NINS pieces of a tile; a piece is RPI rows =
+    // 1 KiB written linearly, lane l -> row l / CPR, slot l % CPR; the slot must hold chunk (slot ^ f(row)), f being
+    // lds_off's swizzle: so the SOURCE address is permuted, the LDS side stays linear.  The swizzle term depends on the
+    // row modulo 16 only, so ONE per-lane byte offset (voffset) serves every DMA of the wave; the tile/piece part is
+    // wave-uniform (soffset) and the slab is described by a buffer resource whose range check turns rows past the end
+    // of the sequence into zeros.
     const int drow = lane / CPR;
     const int dslot = lane % CPR;
     const int prow = wave * RPI + drow;                                   // row inside the tile (first piece)
@@ -498,171 +536,47 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dkdv_kernel(BwdArgs p)
     };
 
     if (t0 < tend) stage(t0, 0);                     // tile t lives in buffer (t - t0) & 1
-    __syncthreads();
 
-    // ---- loop-invariant per-lane LDS offsets
+    // ---- loop-invariant per-lane LDS addresses (byte addresses; buffer / sub-tile parts are immediates in the bodies)
+    const uint32_t lbase = (uint32_t)(uintptr_t)smem;
     const int trq = (lane & 15) >> 2;
     const int trp = lane & 3;
     const int trcb = (lane >> 4) & 1;
-    int roff[KS], toff[DT][2];
-    const char* Vw = smem + 2 * BUFB + 64 * wave * ROWB;          // this wave's 64 V rows (same swizzle phase as row ki)
+    uint32_t roff[KS], toff[2 * DT];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        roff[s] = lds_off<D>(ki, 2 * s + h);                          // A-operand row = query = lane & 31
-    }
+    for (int s = 0; s < KS; ++s) roff[s] = lbase + lds_off<D>(ki, 2 * s + h);                 // A-operand row = query = lane & 31
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-            toff[dt][jj] = lds_off<D>(8 * jj + 4 * h + trq, 4 * dt + 2 * trcb + (trp >> 1)) + 8 * (trp & 1);   // +16 rows: sp = 1
+        for (int jj = 0; jj < 2; ++jj)                                                        // +16 rows: sp = 1
+            toff[2 * dt + jj] = lbase + lds_off<D>(8 * jj + 4 * h + trq, 4 * dt + 2 * trcb + (trp >> 1)) + 8 * (trp & 1);
+    const uint32_t rcadr = lbase + 2 * TILEB + 16 * h;          // rows 8g + 4h .. of a constant plane (the bodies add buffer / sub-tile)
+    // this wave's 64 V rows (same swizzle phase as row ki)
+    static_for<KS>([&](auto S) {
+        constexpr int sidx = decltype(S)::value;
+        dkdv_vset<ROFFV + sidx>(roff[sidx] + 2 * BUFB + 64 * wave * ROWB);
+    });
 
-    // One 32-row sub-tile SH of the 64-row tile t living in buffer BUF.
-    auto sub = [&](auto BUF, auto SH, int t) {
-        constexpr int buf = decltype(BUF)::value;
-        constexpr int sh = decltype(SH)::value;
-        const char* Qt = smem + buf * BUFB + sh * HALFB;
-        const char* Gt = Qt + TILEB;
-        const float* rcs = reinterpret_cast<const float*>(smem + buf * BUFB + 2 * TILEB) + 32 * sh;
+    __syncthreads();                                 // V image written, first tile landed (vmcnt(0) inside)
+    if (t0 < tend) dkdv_prologue<D>(roff, toff, rcadr);
 
-        const int qb0 = t * TROWS + 32 * sh;
-        // accumulators start from the row constants: S' = Q K^T - L/scale, dP' = dO V^T - D
-        // (the constants go into the first key block's tile only; the second chain takes them as its C
-        // operand: mfma2_vv_cinit)
-        f32x16 sacc[2], dpacc[2];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(rcs + 8 * g + 4 * h);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(rcs + 64 + 8 * g + 4 * h);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                sacc[0][4 * g + e] = a[e];
-                dpacc[0][4 * g + e] = b[e];
-            }
-        }
-        // ---- stage A: S'[q][key] for both key blocks, Q row fragments read one k-step ahead
-        bf16x8 qa = lds_read_frag(Qt, roff[0]);
-        static_for<KS>([&](auto S) {
-            constexpr int sidx = decltype(S)::value;
-            bf16x8 qn = qa;
-            if constexpr (sidx + 1 < KS) qn = lds_read_frag(Qt, roff[sidx + 1]);
-            if constexpr (sidx == 0) mfma2_vv_cinit(sacc[0], sacc[1], qa, kf[0][sidx], kf[1][sidx]);
-            else mfma2_vv(sacc[0], sacc[1], qa, kf[0][sidx], kf[1][sidx]);
-            qa = qn;
-        });
-        __builtin_amdgcn_sched_barrier(0);
-
-        // ---- stage B: dP'[q][key] (dO rows x the V image) beside P = exp2(c S') of the finished S'
-        const bool tail = qb0 + kDkQ > Nq;
-        bool diag = false;
-        if (CAUSAL) diag = qb0 < kw0 + 63 - p.causal_shift;
-        constexpr int RPB = 16 / KS;              // S' registers per key block exponentiated beside one k-step
-        bf16x8 ga = lds_read_frag(Gt, roff[0]);
-        bf16x8 v0 = lds_read_frag(Vw, roff[0]), v1 = lds_read_frag(Vw, roff[0] + 32 * ROWB);
-        static_for<KS>([&](auto S) {
-            constexpr int sidx = decltype(S)::value;
-            bf16x8 gn = ga, v0n = v0, v1n = v1;
-            if constexpr (sidx + 1 < KS) {
-                gn = lds_read_frag(Gt, roff[sidx + 1]);
-                v0n = lds_read_frag(Vw, roff[sidx + 1]);
-                v1n = lds_read_frag(Vw, roff[sidx + 1] + 32 * ROWB);
-            }
-            if constexpr (sidx == 0) mfma2_vv_cinit(dpacc[0], dpacc[1], ga, v0, v1);
-            else mfma2_vv(dpacc[0], dpacc[1], ga, v0, v1);
-            __builtin_amdgcn_sched_barrier(0);       // the exponentials stay between this step's MFMAs and the next's
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = sidx * RPB; r < (sidx + 1) * RPB; ++r)    // behind this step's MFMAs; S' retired a stage ago
-                    sacc[kb][r] = __builtin_amdgcn_exp2f(sacc[kb][r] * c2);
-            keep_alive(ga); keep_alive(v0); keep_alive(v1);
-            ga = gn; v0 = v0n; v1 = v1n;
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        thread4(sacc[0], sacc[1], dpacc[0], dpacc[1]);
-        if (tail || diag) {          // wave-uniform and rare: a branch, not 64 selects per tile
-            const int hi = Nq - qb0 - 4 * h;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                const int lo = CAUSAL ? (kw0 + 32 * kb + ki) - p.causal_shift - qb0 - 4 * h : -1;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rr = (r & 3) + 8 * (r >> 2);
-                    if (rr >= hi || rr < lo) sacc[kb][r] = 0.0f;
-                }
-            }
-        }
-        bf16x8 pf[2][2], dsf[2][2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int sp = 0; sp < 2; ++sp) pf[kb][sp] = pack_acc(sacc[kb], sp);
-
-        // ---- stage C: dV^T[dcol][key] += dO^T[dcol][q] P[q][key], group g = (dt, sp), beside
-        // dS = P dP' of the finished dP' (settled first: it is only one stage old)
-        constexpr int QB = buf * BUFB + sh * HALFB, GB = QB + TILEB, SPB = 16 * ROWB;
-        const uint32_t lbase = (uint32_t)(uintptr_t)smem;
-        bf16x4 ta0, ta1;
-        lds_read_tr2_asm<GB>(ta0, ta1, lbase + toff[0][0], lbase + toff[0][1]);
-        mfma_vgpr_settle(dpacc[1]);
-        constexpr int RPC = 16 / (2 * DT);        // dP' registers per key block turned into dS beside one group
-        static_for<2 * DT>([&](auto G) {
-            constexpr int g = decltype(G)::value;
-            constexpr int dt = g >> 1, sp = g & 1;
-            bf16x8 gT;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { gT[e] = ta0[e]; gT[4 + e] = ta1[e]; }
-            bf16x4 tn0, tn1;
-            if constexpr (g + 1 < 2 * DT) {
-                constexpr int dtn = (g + 1) >> 1, spo = ((g + 1) & 1) * SPB;
-                tr_mfma2_acc_next<GB + spo>(tn0, tn1, lbase + toff[dtn][0], lbase + toff[dtn][1], dvacc[0][dt], dvacc[1][dt], gT,
-                                            pf[0][sp], pf[1][sp]);
-            } else {                                    // first Q^T fragment of stage D
-                tr_mfma2_acc_next<QB>(tn0, tn1, lbase + toff[0][0], lbase + toff[0][1], dvacc[0][dt], dvacc[1][dt], gT, pf[0][sp],
-                                      pf[1][sp]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = g * RPC; r < (g + 1) * RPC; ++r) dpacc[kb][r] = sacc[kb][r] * dpacc[kb][r];   // dS[q][key]
-            keep_alive(gT);
-            ta0 = tn0; ta1 = tn1;
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        thread4(sacc[0], sacc[1], dpacc[0], dpacc[1]);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int sp = 0; sp < 2; ++sp) dsf[kb][sp] = pack_acc(dpacc[kb], sp);
-
-        // ---- stage D: dK^T[dcol][key] += Q^T[dcol][q] dS[q][key]  (the first group reads dS fragments the
-        // VALU packed a moment ago: padded)
-        static_for<2 * DT>([&](auto G) {
-            constexpr int g = decltype(G)::value;
-            constexpr int dt = g >> 1, sp = g & 1;
-            bf16x8 qT;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { qT[e] = ta0[e]; qT[4 + e] = ta1[e]; }
-            if constexpr (g + 1 < 2 * DT) {
-                constexpr int dtn = (g + 1) >> 1, spo = ((g + 1) & 1) * SPB;
-                bf16x4 tn0, tn1;
-                tr_mfma2_acc_next<QB + spo, g == 0>(tn0, tn1, lbase + toff[dtn][0], lbase + toff[dtn][1], dkacc[0][dt], dkacc[1][dt],
-                                                    qT, dsf[0][sp], dsf[1][sp]);
-                ta0 = tn0; ta1 = tn1;
-            } else {
-                tr_mfma2_acc_last(dkacc[0][dt], dkacc[1][dt], qT, dsf[0][sp], dsf[1][sp]);
-            }
-        });
-    };
     auto tile = [&](auto BUF, int t) {
         constexpr int buf = decltype(BUF)::value;
+        __builtin_amdgcn_s_barrier();                // B1: nobody reads the other buffer any more
         if (t + 1 < tend) stage(t + 1, buf ^ 1);
-        sub(BUF, std::integral_constant<int, 0>{}, t);
-        sub(BUF, std::integral_constant<int, 1>{}, t);
-        // hipcc may copy a pinned accumulator register (v_accvgpr_mov at the loop back-edge) without
-        // knowing an MFMA is still writing it: let the last MFMAs of the tile retire first.
-        mfma_acc_settle();
-        __syncthreads();     // drains this wave's DMA (vmcnt) and hands the buffers over
+        const int q0t = t * TROWS;
+        bool masked = q0t + TROWS > Nq;
+        if (CAUSAL) masked = masked || q0t < kw0 + 63 - p.causal_shift;
+        if (masked) {                                // wave-uniform and rare
+            const int hi = Nq - q0t - 4 * h;
+            const int lo0 = CAUSAL ? kw0 + ki - p.causal_shift - q0t - 4 * h : -(1 << 30);
+            const int lo1 = CAUSAL ? lo0 + 32 : lo0;
+            dkdv_body<D, buf, 0, true>(roff, toff, rcadr, c2, hi, lo0, lo1);
+            dkdv_body<D, buf, 1, true>(roff, toff, rcadr, c2, hi, lo0, lo1);
+        } else {
+            dkdv_body<D, buf, 0, false>(roff, toff, rcadr, c2, 0, 0, 0);
+            dkdv_body<D, buf, 1, false>(roff, toff, rcadr, c2, 0, 0, 0);
+        }
     };
 
     for (int t = t0; t < tend; t += 2) {
@@ -670,28 +584,27 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dkdv_kernel(BwdArgs p)
         tile(std::integral_constant<int, 1>{}, t + 1);
     }
 
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the last body's look-ahead reads
     mfma_acc_settle();
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    static_for<2>([&](auto KB) {
+        constexpr int kb = decltype(KB)::value;
         const int key = kw0 + 32 * kb + ki;
-        if (key < N) {
-            char* dKk = (char*)p.dK + slab + (size_t)key * ROWB;
-            char* dVk = (char*)p.dV + slab + (size_t)key * ROWB;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    bf16x4 a, b;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        a[e] = (__bf16)(dkacc[kb][dt][4 * g + e] * p.scale);
-                        b[e] = (__bf16)dvacc[kb][dt][4 * g + e];
-                    }
-                    *reinterpret_cast<bf16x4*>(dKk + 2 * (32 * dt + 8 * g + 4 * h)) = a;
-                    *reinterpret_cast<bf16x4*>(dVk + 2 * (32 * dt + 8 * g + 4 * h)) = b;
-                }
-        }
-    }
+        char* dKk = (char*)p.dK + slab + (size_t)(key < N ? key : 0) * ROWB;
+        char* dVk = (char*)p.dV + slab + (size_t)(key < N ? key : 0) * ROWB;
+        static_for<4 * DT>([&](auto G) {
+            constexpr int dt = decltype(G)::value / 4, g = decltype(G)::value % 4;
+            constexpr int RK = A_DK + 16 * (kb * DT + dt) + 4 * g, RV = A_DV + 16 * (kb * DT + dt) + 4 * g;
+            bf16x4 a, b;
+            a[0] = (__bf16)(acc_read<RK>() * p.scale); a[1] = (__bf16)(acc_read<RK + 1>() * p.scale);
+            a[2] = (__bf16)(acc_read<RK + 2>() * p.scale); a[3] = (__bf16)(acc_read<RK + 3>() * p.scale);
+            b[0] = (__bf16)acc_read<RV>(); b[1] = (__bf16)acc_read<RV + 1>();
+            b[2] = (__bf16)acc_read<RV + 2>(); b[3] = (__bf16)acc_read<RV + 3>();
+            if (key < N) {
+                *reinterpret_cast<bf16x4*>(dKk + 2 * (32 * dt + 8 * g + 4 * h)) = a;
+                *reinterpret_cast<bf16x4*>(dVk + 2 * (32 * dt + 8 * g + 4 * h)) = b;
+            }
+        });
+    });
 }
 
 // --------------------------------------------------------------------------- launch

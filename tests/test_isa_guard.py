@@ -1,0 +1,154 @@
+"""CPU: a guard over the GENERATED gfx950 code of the hot kernels (no GPU needed: `make asm` emits the device assembly
+with the very flags of the shipped objects).
+
+The kernels own literal accumulator registers (a[0:127] / a[0:255]), count LDS / MFMA wait states by hand and rely on
+hipcc keeping out of their way; a clobber list says "this statement destroys a12", it does not reserve a12.  What
+stands between a compiler bump and silently wrong O / dQ / dK / dV is therefore checked here, on every build:
+
+  * no scratch, no VGPR spill in any product kernel;
+  * in the kernels that name their AGPRs, no compiler-generated instruction touches the accumulator file -- every
+    `a[..]` / `v_accvgpr_*` sits between ;;#ASMSTART and ;;#ASMEND;
+  * the hot loops hold exactly the MFMAs the algorithm needs (a dropped or duplicated stage shows up here);
+  * no `s_nop` inside the MFMA stages of the forward (each is an issue slot the loop cannot afford), and the
+    register budget of the two-waves-per-SIMD kernels stays within 128 + 128.
+
+fa2_version() carries the compiler version so a report names the toolchain that built the library."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "cuda_flashattention_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def asm():
+    subprocess.check_call(["make", "-s", "-j", "4", "-C", CSRC, "asm"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    out = {}
+    for f in ("fa2_fwd_bf16", "fa2_bwd_bf16", "fa2_fwd_fp8", "fa2_f32", "fa2_util"):
+        out[f] = open(os.path.join(CSRC, "_obj", f + ".s")).read()
+    return out
+
+
+def _kernels(text):
+    """name -> dict(body=[lines], meta={...}) for every kernel of one .s file."""
+    ks = {}
+    for m in re.finditer(r"^(_Z\w+):.*?\n(.*?)\n\s*s_endpgm", text, flags=re.S | re.M):
+        ks[m.group(1)] = {"body": m.group(2).split("\n")}
+    for m in re.finditer(r"- \.agpr_count:\s+(\d+)(.*?)\.wavefront_size", text, flags=re.S):
+        body = m.group(2)
+        name = re.search(r"\.name:\s+(\S+)", body).group(1)
+        g = lambda k: int(re.search(r"\." + k + r":\s+(\d+)", body).group(1))
+        ks[name]["meta"] = dict(agpr=int(m.group(1)), total=g("vgpr_count"), scratch=g("private_segment_fixed_size"),
+                                vgpr_spill=g("vgpr_spill_count"), sgpr=g("sgpr_count"))
+    return ks
+
+
+def _split_asm(body):
+    """(compiler_lines, asm_blocks): instructions outside / inside ;;#ASMSTART .. ;;#ASMEND."""
+    outside, blocks, cur = [], [], None
+    for l in body:
+        s = l.strip()
+        if s.startswith(";;#ASMSTART"):
+            cur = []
+        elif s.startswith(";;#ASMEND"):
+            blocks.append(cur)
+            cur = None
+        elif cur is not None:
+            cur.append(s)
+        elif s and not s.startswith(";") and not s.startswith("."):
+            outside.append(s)
+    return outside, blocks
+
+
+def _main_loop(body):
+    """Lines of the hot loop: among the loops (label .. last backward branch to it) holding at least half as many MFMAs
+    as the richest one, the shortest."""
+    cands = []
+    for i, l in enumerate(body):
+        m = re.match(r"^(\.LBB\d+_\d+):", l)
+        if not m:
+            continue
+        tails = [j for j in range(i, len(body)) if re.match(r"\s+s_c?branch\S*\s+" + re.escape(m.group(1)) + r"\b", body[j])]
+        if tails:
+            cands.append((sum("v_mfma" in t for t in body[i:tails[-1]]), tails[-1] - i, i, tails[-1]))
+    top = max(c[0] for c in cands)
+    _, _, lo, hi = min((c for c in cands if c[0] * 2 >= top), key=lambda c: c[1])
+    return body[lo:hi]
+
+
+PRODUCT = ("fa2_fwd_bf16", "fa2_bwd_bf16", "fa2_fwd_fp8", "fa2_f32", "fa2_util")
+
+
+def test_no_scratch_no_spill(asm):
+    bad = []
+    for f in PRODUCT:
+        for name, k in _kernels(asm[f]).items():
+            if k["meta"]["scratch"] or k["meta"]["vgpr_spill"]:
+                bad.append((name, k["meta"]))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("file,pattern", [("fa2_fwd_bf16", "fa2_fwd_bf16_kernel"), ("fa2_bwd_bf16", "fa2_bwd_dq_kernel"),
+                                          ("fa2_bwd_bf16", "fa2_bwd_dkdv_kernel")])
+def test_accumulator_file_is_touched_by_asm_only(asm, file, pattern):
+    """The kernels that name literal AGPRs: nothing hipcc generates may read, write, copy or spill an accumulator."""
+    ks = {n: k for n, k in _kernels(asm[file]).items() if pattern in n}
+    assert ks
+    for name, k in ks.items():
+        outside, blocks = _split_asm(k["body"])
+        hits = [s for s in outside if re.search(r"v_accvgpr|\ba\[\d+|\ba\d+\b", s)]
+        assert not hits, (name, hits[:5])
+        assert any("v_mfma" in s for b in blocks for s in b)
+
+
+def test_forward_loop_shape(asm):
+    ks = _kernels(asm["fa2_fwd_bf16"])
+    for D, mfmas in ((128, 96), (64, 48)):          # 3 tiles x 2 half-tile steps x (S^T: D/16 + O^T: D/16) MFMAs
+        for causal in (0, 1):
+            for state in (0, 1):
+                name = next(n for n in ks if f"fa2_fwd_bf16_kernelILi{D}ELb{causal}ELb{state}E" in n)
+                loop = _main_loop(ks[name]["body"])
+                assert sum("v_mfma_f32_32x32x16_bf16" in l for l in loop) == mfmas, name
+                _, blocks = _split_asm(loop)
+                for b in blocks:
+                    if any("v_mfma" in s for s in b):
+                        assert not any(s.startswith("s_nop") for s in b), (name, "s_nop inside an MFMA stage")
+                m = ks[name]["meta"]
+                assert m["agpr"] <= 128 and m["total"] <= 256, (name, m)      # two waves per SIMD
+
+
+def test_backward_loop_shape(asm):
+    ks = _kernels(asm["fa2_bwd_bf16"])
+    for D in (128, 64):
+        ksteps, dts = D // 16, D // 32
+        for causal in (0, 1):
+            dq = next(n for n in ks if f"fa2_bwd_dq_kernelILi{D}ELb{causal}E" in n)
+            # per 64-key tile and wave: S^T and dP^T 2 x 2 x ksteps each, dQ^T 2 x 2 x 2 x dts; two tiles, and the
+            # masked variant of each tile is a second copy of the body
+            per_tile = 8 * ksteps + 8 * dts
+            n = sum("v_mfma_f32_32x32x16_bf16" in l for l in _main_loop(ks[dq]["body"]))
+            assert n % per_tile == 0 and 2 <= n // per_tile <= 4, (dq, n)
+            dk = next(n for n in ks if f"fa2_bwd_dkdv_kernelILi{D}ELb{causal}E" in n)
+            # per 32-row sub-tile and wave: S', dP' 2 x ksteps each, dV^T, dK^T 2 x 2 x dts each (generated bodies)
+            per_sub = 4 * ksteps + 8 * dts
+            n = sum("v_mfma_f32_32x32x16_bf16" in l for l in _main_loop(ks[dk]["body"]))
+            assert n == 8 * per_sub, (dk, n)      # two tiles x two sub-tiles, plain and masked bodies
+
+
+def test_fp8_loop_budget(asm):
+    ks = _kernels(asm["fa2_fwd_fp8"])
+    for name, k in ks.items():
+        if "fa2_fwd_fp8_kernel" in name:
+            assert k["meta"]["agpr"] <= 128 and k["meta"]["total"] <= 256, (name, k["meta"])
+            assert any("v_mfma_f32_32x32x64_f8f6f4" in l for l in _main_loop(k["body"]))
+
+
+def test_version_names_the_compiler():
+    import ctypes
+    lib = ctypes.CDLL(os.path.join(ROOT, "cuda_flashattention_amd", "lib", "libfa2_mi355x.so"))
+    lib.fa2_version.restype = ctypes.c_char_p
+    v = lib.fa2_version().decode()
+    assert "gfx950" in v and "clang" in v and re.search(r"hip \d+\.\d+", v), v
