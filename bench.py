@@ -33,14 +33,10 @@ PEAK_BF16_TFLOPS = 2516.6   # MI355X dense bf16 MFMA: 256 CU x 4096 flop/clk x 2
 # operands (tools/probes/mfma_power.hip): the clock settles near 1.77 GHz.  Reported beside the
 # nominal peak; `frac` is always against the nominal one.
 SUSTAINED_MFMA_TFLOPS = 1840.0
-# HBM bytes per launch from the PMC passes in profiles/r1_d_pmc_summary.txt (FETCH_SIZE doubled as
-# MI355X_MICROARCH.md prescribes for gfx950, plus WRITE_SIZE; units of 1024 B).  Collected with
-# rocprofv3 in separate passes, not inside this script.
-PMC_TRAFFIC_BYTES = {
-    "fa2_fwd_bf16_kernel": (2 * 196905 + 133120) * 1024,
-    "fa2_bwd_dq_kernel": (2 * 264344 + 131072) * 1024,
-    "fa2_bwd_dkdv_kernel": (2 * 268507 + 270352) * 1024,
-}
+# HBM bytes per launch come from the rocprofv3 --pmc passes (separate runs, MI355X_MICROARCH.md: FETCH_SIZE doubled on
+# gfx950, plus WRITE_SIZE), summarised by tools/pmc_summary.py into this file; the JSON line names it.  A kernel that
+# is not in the file (the profile predates it) reports traffic null rather than a stale constant.
+PMC_TRAFFIC_FILE = os.path.join("profiles", "pmc_traffic.json")
 B, H, N, D = 4, 16, 8192, 128
 
 
@@ -65,6 +61,22 @@ def timed(fn, iters, torch):
     e1.record()
     e1.synchronize()
     return e0.elapsed_time(e1) / iters
+
+
+def pmc_traffic(kernel):
+    try:
+        with open(os.path.join(ROOT, PMC_TRAFFIC_FILE)) as f:
+            tab = json.load(f)
+        ent = tab["kernels"].get(kernel)
+        return (ent["bytes_per_launch"], tab.get("source")) if ent else (None, tab.get("source"))
+    except (OSError, ValueError, KeyError):
+        return None, None
+
+
+def median_ms(fn, torch, repeats=3, iters=10):
+    """Median over `repeats` timings of `iters` launches each (HIP events on the launch stream)."""
+    vals = sorted(timed(fn, iters, torch) for _ in range(repeats))
+    return vals[len(vals) // 2]
 
 
 def cpu_baseline(torch):
@@ -141,10 +153,10 @@ def main():
     torch.cuda.synchronize()
     it = max(5, min(args.steps, 10))
     k_ms = {
-        "fa2_fwd_bf16_kernel": timed(fwd, it, torch),
-        "fa2_bwd_delta_kernel": timed(lambda: bwd(1), it, torch),
-        "fa2_bwd_dq_kernel": timed(lambda: bwd(2), it, torch),
-        "fa2_bwd_dkdv_kernel": timed(lambda: bwd(4), it, torch),
+        "fa2_fwd_bf16_kernel": median_ms(fwd, torch, 3, it),
+        "fa2_bwd_delta_kernel": median_ms(lambda: bwd(1), torch, 3, it),
+        "fa2_bwd_dq_kernel": median_ms(lambda: bwd(2), torch, 3, it),
+        "fa2_bwd_dkdv_kernel": median_ms(lambda: bwd(4), torch, 3, it),
     }
     for _ in range(args.warmup):
         step()
@@ -165,17 +177,23 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * flops_step / (ms_per_step * 1e-3) / 1e12
 
-    # MFMA flops each launch executes: fwd 2 block products, dq 3 (S, dP, dQ), dkdv 4 (S, dP, dV, dK)
+    # MFMA flops each launch executes: fwd 2 block products, dq 3 (S, dP, dQ), dkdv 4 (S, dP, dV, dK); and the
+    # ALGORITHMIC flops each delivers (the five products of the backward counted once: dQ to the dq kernel, the other
+    # four to dkdv, whose products are all among the five).
     prod = 2.0 * B * H * N * N * D
     k_flops = {"fa2_fwd_bf16_kernel": 2 * prod, "fa2_bwd_dq_kernel": 3 * prod, "fa2_bwd_dkdv_kernel": 4 * prod}
+    k_alg = {"fa2_fwd_bf16_kernel": 2 * prod, "fa2_bwd_dq_kernel": 1 * prod, "fa2_bwd_dkdv_kernel": 4 * prod}
     dom = max(k_flops, key=lambda k: k_ms[k])
-    achieved = k_flops[dom] / (k_ms[dom] * 1e-3) / 1e12
+    achieved = k_alg[dom] / (k_ms[dom] * 1e-3) / 1e12
+    traffic, traffic_src = pmc_traffic(dom)
     roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                "traffic": PMC_TRAFFIC_BYTES.get(dom), "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
+                "traffic": traffic, "traffic_unit": "bytes/launch (rocprofv3 PMC)", "traffic_source": traffic_src and PMC_TRAFFIC_FILE,
                 "sustained_mfma_peak": SUSTAINED_MFMA_TFLOPS, "frac_of_sustained": round(achieved / SUSTAINED_MFMA_TFLOPS, 4),
-                "flops_per_launch": k_flops[dom], "ms_per_launch": round(k_ms[dom], 4),
+                "flops_per_launch": k_alg[dom], "ms_per_launch": round(k_ms[dom], 4),
                 "kernels_ms": {k: round(v, 4) for k, v in k_ms.items()},
+                "kernels_frac_executed": {k: round(k_flops[k] / (k_ms[k] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) for k in k_flops},
+                "kernels_frac_algorithmic": {k: round(k_alg[k] / (k_ms[k] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) for k in k_alg},
                 "whole_path_frac": round(value / world / PEAK_BF16_TFLOPS, 4)}
 
     out = {
@@ -190,13 +208,7 @@ def main():
         "roofline": roofline,
     }
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        try:
-            out["cpu_baseline"] = cpu_baseline(torch)
-        except Exception as e:  # the baseline is a reported side figure, never fatal
-            out["cpu_baseline"] = {"error": repr(e)}
-
-    # ---- side figures SURVEY 8d asks for beside the headline: forward only at BASELINE configs[1] (bf16)
+    # ---- side figures SURVEY 8d asks for beside the headline (timed BEFORE the CPU baseline idles the GPU): forward only at BASELINE configs[1] (bf16)
     # and the fp8 causal forward of configs[4] (B and H unspecified there: B=1, H=16)
     if rank == 0:
         try:
@@ -207,16 +219,22 @@ def main():
                 o = torch.empty(Bx, Hx, Nx, dx, dtype=torch.bfloat16, device=dev)
                 l = torch.empty(Bx, Hx, Nx, dtype=torch.float32, device=dev)
                 f = lambda: fa.flash_attention_2_forward(q, k, v, None, causal=causal, O=o, L=l)
-                for _ in range(8):          # the GPU idled during the CPU baseline: let the clocks come back
+                for _ in range(50):         # code-object load and clock ramp stay out of the timings
                     f()
-                ms = timed(f, 10, torch)
+                ms = median_ms(f, torch, 3, 20)          # median of three runs of 20 launches
                 fl = 4.0 * Bx * Hx * Nx * Nx * dx * (0.5 if causal else 1.0)
-                return {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1)}
+                return {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1), "timing": "median of 3 x 20 launches after 50 warm-up launches"}
             extra["fwd_bf16_cfg2_(4,16,4096,64)"] = fwd_only(4, 16, 4096, 64, torch.bfloat16, False)
             extra["fwd_fp8_e4m3_causal_cfg5_(1,16,32768,128)"] = fwd_only(1, 16, 32768, 128, torch.float8_e4m3fn, True)
             out["side_figures"] = extra
         except Exception as e:
             out["side_figures"] = {"error": repr(e)}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(torch)
+        except Exception as e:  # the baseline is a reported side figure, never fatal
+            out["cpu_baseline"] = {"error": repr(e)}
 
     # The ring leg is a side figure: it must never take the headline line down with it.  It runs in a
     # worker thread under a deadline; if the transport wedges (an RCCL hang cannot be interrupted) the
@@ -240,13 +258,17 @@ def main():
         hung = th.is_alive()
         if hung:
             out["ring"] = {"error": "ring leg did not finish within its deadline; skipped"}
+            out["ring_hang"] = True
         elif box.get("ring") is not None:
             out["ring"] = box["ring"]
 
     if rank == 0:
         print(json.dumps(out), flush=True)
     sys.stdout.flush()
-    if hung or (dist is not None and not args.no_ring):
+    if hung:
+        # A wedged transport must not look like a clean run: the headline line is out, the exit status says so.
+        os._exit(3)
+    if dist is not None and not args.no_ring:
         # After a ring leg the ranks may disagree on whether it finished (each has its own deadline): no
         # further collective, every rank simply leaves.  The timed region and its barriers are long past.
         os._exit(0)

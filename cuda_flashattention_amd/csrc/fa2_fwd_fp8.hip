@@ -431,8 +431,10 @@ __global__ void __launch_bounds__(64 * kF8Waves, 1) fa2_fwd_fp8_kernel(FwdFp8Arg
         tile(std::integral_constant<int, 2>{}, T + 2);
     }
 
-    // ---- epilogue
+    // ---- epilogue.  The lane half is recomputed (v_mbcnt) rather than kept from kernel entry: a value that is live
+    // across the whole loop only to be used here gets spilled to scratch at this register budget.
     mfma_acc_settle();
+    const int h_ep = (int)(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) >> 5);
     const float l_tot = half_sum(l_run);
     const size_t qoff = (size_t)head * N + qrow;
     const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
@@ -446,10 +448,10 @@ __global__ void __launch_bounds__(64 * kF8Waves, 1) fa2_fwd_fp8_kernel(FwdFp8Arg
             bf16x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
-            *reinterpret_cast<bf16x4*>((char*)p.O + qoff * (kF8D * 2) + 2 * (32 * dt + 8 * g + 4 * h)) = o;
+            *reinterpret_cast<bf16x4*>((char*)p.O + qoff * (kF8D * 2) + 2 * (32 * dt + 8 * g + 4 * h_ep)) = o;
         }
     });
-    if (qrow < N && h == 0) p.L[qoff] = m_run + __builtin_logf(l_tot);
+    if (qrow < N && h_ep == 0) p.L[qoff] = m_run + __builtin_logf(l_tot);
 }
 #undef FA2_F8_QUAD
 

@@ -30,10 +30,12 @@ def _stream_ptr(stream=None):
 
 
 def _bhnd(x, name):
+    if not isinstance(x, torch.Tensor):
+        raise ValueError(f"{name} must be a torch tensor")
     if not x.is_cuda:
         raise ValueError(f"{name} must be a device tensor")
     if not x.is_contiguous():
-        raise ValueError(f"{name} must be contiguous [B][H][N][d]")
+        raise ValueError(f"{name} must be contiguous [B][H][N][d] (got strides {tuple(x.stride())}; call .contiguous())")
     if x.dim() == 2:
         return 1, 1, x.shape[0], x.shape[1]
     if x.dim() == 4:
@@ -41,19 +43,41 @@ def _bhnd(x, name):
     raise ValueError(f"{name}: expected [N,d] or [B,H,N,d], got {tuple(x.shape)}")
 
 
+def _like(x, name, ref, shape, dtype):
+    """The C ABI takes raw pointers: everything it will read or write as a dense [B][H][N][d] (or [B][H][N]) tensor is
+    checked here -- device, contiguity, shape, dtype -- instead of becoming a silent out-of-bounds access."""
+    if _bhnd(x, name) != shape and tuple(x.shape) != shape:
+        raise ValueError(f"{name}: shape {tuple(x.shape)} does not match {shape}")
+    if x.dtype != dtype:
+        raise ValueError(f"{name}: dtype {x.dtype}, expected {dtype}")
+    if x.device != ref.device:
+        raise ValueError(f"{name} is on {x.device}, expected {ref.device}")
+    return x
+
+
+def _rows(x, name, ref, B, H, N):
+    if not isinstance(x, torch.Tensor) or not x.is_cuda or not x.is_contiguous():
+        raise ValueError(f"{name} must be a contiguous device tensor")
+    if x.dtype != torch.float32 or x.numel() != B * H * N or x.device != ref.device:
+        raise ValueError(f"{name}: expected fp32 [B,H,N] = {B * H * N} elements on {ref.device}, got {x.dtype} {tuple(x.shape)}")
+    return x
+
+
 def flash_attention_2_forward(Q, K, V, softmax_scale=None, causal=False, O=None, L=None, stream=None):
     """O, L = FA2 forward.  Mirrors flash_attention_2_forward(Q,K,V,O,L,seq_len,head_dim,scale)
     (reference 02_forward/flash_attention_kernel.cu:300-309) with B,H,dtype,causal,stream added.
     Tensors [N,d] or [B,H,N,d]; L is fp32 [.., N] natural-log LSE."""
-    B, H, N, d = _bhnd(Q, "Q")
+    B, H, N, d = shape = _bhnd(Q, "Q")
     for n, t in (("K", K), ("V", V)):
-        if _bhnd(t, n) != (B, H, N, d) or t.dtype != Q.dtype:
-            raise ValueError(f"{n} must match Q in shape and dtype")
+        _like(t, n, Q, shape, Q.dtype)
     scale = float(softmax_scale) if softmax_scale is not None else 1.0 / math.sqrt(d)
-    if O is None:     # fp8 inputs (OCP e4m3, d = 128, BASELINE configs[4]) produce a bf16 O
-        O = torch.empty(Q.shape, dtype=torch.bfloat16, device=Q.device) if Q.dtype == torch.float8_e4m3fn else torch.empty_like(Q)
+    odt = torch.bfloat16 if Q.dtype == torch.float8_e4m3fn else Q.dtype      # fp8 inputs (OCP e4m3, d = 128) produce a bf16 O
+    if O is None:
+        O = torch.empty(Q.shape, dtype=odt, device=Q.device)
     if L is None:
         L = torch.empty(Q.shape[:-1], dtype=torch.float32, device=Q.device)
+    _like(O, "O", Q, shape, odt)
+    _rows(L, "L", Q, B, H, N)
     st = _capi.lib().fa2_forward(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), L.data_ptr(),
                                  B, H, N, d, scale, _dtype_code(Q), 1 if causal else 0, _stream_ptr(stream))
     check(st, "fa2_forward")
@@ -63,16 +87,22 @@ def flash_attention_2_forward(Q, K, V, softmax_scale=None, causal=False, O=None,
 def flash_attention_2_backward(Q, K, V, O, L, dO, softmax_scale=None, causal=False,
                                dQ=None, dK=None, dV=None, workspace=None, stream=None, phases=7):
     """dQ, dK, dV = FA2 backward.  Mirrors flash_attention_2_backward(Q,K,V,O,L,dO,dQ,dK,dV,...)
-    (reference 02_backward/flash_attention_backward_kernel.cu:249-262)."""
-    B, H, N, d = _bhnd(Q, "Q")
+    (reference 02_backward/flash_attention_backward_kernel.cu:249-262).  dO must be contiguous (autograd often hands
+    over an expanded or transposed view: call .contiguous() on it first -- the C ABI reads a dense tensor)."""
+    B, H, N, d = shape = _bhnd(Q, "Q")
+    for n, t in (("K", K), ("V", V), ("O", O), ("dO", dO)):
+        _like(t, n, Q, shape, Q.dtype)
+    _rows(L, "L", Q, B, H, N)
     scale = float(softmax_scale) if softmax_scale is not None else 1.0 / math.sqrt(d)
-    dQ = torch.empty_like(Q) if dQ is None else dQ
-    dK = torch.empty_like(K) if dK is None else dK
-    dV = torch.empty_like(V) if dV is None else dV
+    dQ = torch.empty_like(Q) if dQ is None else _like(dQ, "dQ", Q, shape, Q.dtype)
+    dK = torch.empty_like(K) if dK is None else _like(dK, "dK", Q, shape, Q.dtype)
+    dV = torch.empty_like(V) if dV is None else _like(dV, "dV", Q, shape, Q.dtype)
     lib = _capi.lib()
     need = lib.fa2_backward_workspace_bytes(B, H, N, d, _dtype_code(Q))
     if workspace is None:
         workspace = torch.empty(need, dtype=torch.uint8, device=Q.device)
+    if not isinstance(workspace, torch.Tensor) or not workspace.is_cuda or not workspace.is_contiguous() or workspace.device != Q.device:
+        raise ValueError("workspace must be a contiguous device tensor on Q's device")
     st = lib.fa2_backward_phases(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), L.data_ptr(),
                                  dO.data_ptr(), dQ.data_ptr(), dK.data_ptr(), dV.data_ptr(),
                                  B, H, N, d, scale, _dtype_code(Q), 1 if causal else 0,
@@ -84,8 +114,18 @@ def flash_attention_2_backward(Q, K, V, O, L, dO, softmax_scale=None, causal=Fal
 
 def forward_step(Q, K, V, O, L, Oacc, M, softmax_scale, first, last, stream=None):
     """One resumable ring step (ring_attention_forward_kernel, ring_attention_kernel.cu:13-140)."""
-    B, H, Nq, d = _bhnd(Q, "Q")
-    _, _, Nk, _ = _bhnd(K, "K")
+    B, H, Nq, d = qshape = _bhnd(Q, "Q")
+    _, _, Nk, _ = kshape = _bhnd(K, "K")
+    if kshape != (B, H, Nk, d) or K.dtype != Q.dtype:
+        raise ValueError("K must match Q in B, H, d and dtype")
+    _like(V, "V", Q, kshape, Q.dtype)
+    if O is not None:
+        _like(O, "O", Q, qshape, Q.dtype)
+    _rows(L, "L", Q, B, H, Nq)
+    if Oacc is not None:
+        _like(Oacc, "Oacc", Q, qshape, torch.float32)
+    if M is not None:
+        _rows(M, "M", Q, B, H, Nq)
     st = _capi.lib().fa2_forward_step(Q.data_ptr(), K.data_ptr(), V.data_ptr(),
                                       O.data_ptr() if O is not None else None, L.data_ptr(),
                                       Oacc.data_ptr() if Oacc is not None else None,

@@ -65,6 +65,9 @@ def test_03_ring_reference_case_and_verify():
     assert rc == 0 and "Ring verify PASSED" in out, out
     rc, out = run("02_overlap", 1, 4, 1024, 128, 2)
     assert rc == 0 and "Overlap test completed!" in out and "Received block starting with 1 (expected 1 from rank 0)" in out, out
+    rc, out = run("03_attention_1GPU")          # run.sh 3: single-GPU forward vs naive on the ring test's data
+    assert rc == 0 and "=== Comparison: Naive vs FlashAttention ===" in out and "Test PASSED!" in out, out
+    assert "WARNING" not in out and "Each GPU processes" in out
     rc, out = run("04_ring_attention")
     assert rc == 0, out
     assert "All outputs match within tolerance (rtol=5.0e-03, atol=1.0)" in out and "Test PASSED!" in out

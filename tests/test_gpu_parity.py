@@ -254,6 +254,100 @@ def test_full_size_sampled_rows_and_properties():
     _, dQr, _, _ = oracle.fwdbwd_rows(f32(Q[b, h]), f32(K[b, h]), f32(V[b, h]), f32(dO[b, h]), s, rows=(7, 128))
     sel = np.arange(7, N, 128)
     assert rel(f32(dQ[b, h])[sel], dQr.astype(np.float64)) <= BF16_REL
+    # (iv) ONE WHOLE HEAD of the backward at this size against the oracle (about 110 GFLOP of CPU work): dK and dV
+    # need every query row, so this is what exercises the dK/dV kernel's full 128-tile sweep, its tile padding and
+    # its row-constant DMA offsets at the very shape the headline is quoted on.  Gate: 02_backward/main.cu:292-298
+    # (max |d| < 5e-3) and the bf16 rel-L2 gate.
+    for (b, h) in ((3, 9),):
+        ref = oracle.attention_backward(f32(Q[b, h]), f32(K[b, h]), f32(V[b, h]), f32(dO[b, h]), s)
+        for name, got, want in zip(("dQ", "dK", "dV"), (dQ, dK, dV), ref):
+            assert rel(f32(got[b, h]), want) <= BF16_REL, name
+            assert np.abs(f32(got[b, h]) - want).max() < 5e-3, name
+
+
+def test_forward_config2_full_size_sampled_rows():
+    """BASELINE configs[1]: FA2 forward bf16 at (4,16,4096,64) -- d = 64 at full size (the oracle comparison of the
+    shape sweep stops at N = 1024): every 32nd row of three heads, all of L finite, gate 02_forward/main.cu:89."""
+    fa, oracle = _fa(), _oracle()
+    B, H, N, d = 4, 16, 4096, 64
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(17)
+    mk = lambda: (torch.rand(B, H, N, d, device=dev, generator=g) - 0.5).bfloat16()
+    Q, K, V = mk(), mk(), mk()
+    s = 1.0 / d ** 0.5
+    O, L = fa.flash_attention_2_forward(Q, K, V, s)
+    torch.cuda.synchronize()
+    assert torch.isfinite(O.float()).all() and torch.isfinite(L).all()
+    for (b, h, off) in ((0, 3, 1), (2, 8, 17), (3, 15, 31)):
+        Or, Lr = oracle.attention_forward(f32(Q[b, h]), f32(K[b, h]), f32(V[b, h]), s, rows=(off, 32))
+        sel = np.arange(off, N, 32)
+        assert rel(f32(O[b, h])[sel], Or[sel]) <= BF16_REL
+        assert np.abs(f32(O[b, h])[sel] - Or[sel]).max() < 5e-3
+        assert np.abs(L[b, h].cpu().numpy()[sel] - Lr[sel]).max() <= 1e-4
+
+
+def _np_block_backward(Q, K, V, O, L, dO, scale, causal, shift):
+    """Whole-precision restatement of one block of flash_attention_backward_kernel.cu:97-231 (P from the given L)."""
+    q, k, v, o, g = (a.astype(np.float64) for a in (Q, K, V, O, dO))
+    P = np.exp(scale * q @ k.T - L.astype(np.float64)[:, None])
+    if causal:
+        P[np.arange(k.shape[0])[None, :] > np.arange(q.shape[0])[:, None] + shift] = 0.0
+    dS = P * (g @ v.T - (g * o).sum(1)[:, None])
+    return scale * dS @ k, scale * dS.T @ q, P.T @ g
+
+
+@pytest.mark.parametrize("d,nq,nk,q_row0,q_hs,k_hs,causal,shift", [
+    (128, 192, 320, 64, 320, 400, False, 0),      # a row range of every head against a longer key range
+    (64, 200, 100, 0, 200, 100, False, 0),        # more rows than keys, ragged both ways
+    (128, 256, 256, 0, 256, 256, True, -64),      # causal with a NEGATIVE shift (first rows see nothing)
+    (64, 130, 300, 70, 200, 300, True, 100),      # causal with a positive shift, strided rows
+])
+def test_backward_block_rectangular(d, nq, nk, q_row0, q_hs, k_hs, causal, shift):
+    """fa2_backward_block: q_len != kv_len, head strides, a row offset into the workspace planes and a causal shift --
+    the unit of work of the (causal) ring backward -- against the numpy restatement, with L = the block's own
+    log-sum-exp shifted by a per-row constant (as if other key blocks existed)."""
+    fa = _fa()
+    from cuda_flashattention_amd import _capi
+    B, H = 1, 3
+    g = torch.Generator().manual_seed(nq + nk)
+    mkt = lambda n, sc: ((torch.rand(B, H, n, d, generator=g) - 0.5) * sc).bfloat16()
+    Qf, Of, Gf = mkt(q_hs, 1.0), mkt(q_hs, 0.2), mkt(q_hs, 0.4)
+    Kf, Vf = mkt(k_hs, 1.0), mkt(k_hs, 1.0)
+    s = 1.0 / d ** 0.5
+    # L: log-sum-exp of the visible scores plus 0.3 (extra mass elsewhere); rows that see nothing get a finite value
+    S = s * (Qf.float() @ Kf[:, :, :nk].float().transpose(-1, -2))[:, :, q_row0:q_row0 + nq]
+    if causal:
+        mask = torch.arange(nk)[None, :] > torch.arange(nq)[:, None] + shift
+        S = S.masked_fill(mask, float("-inf"))
+    Lb = torch.logsumexp(S, -1)
+    Lb = torch.where(torch.isfinite(Lb), Lb, torch.zeros_like(Lb)) + 0.3
+    Lfull = torch.zeros(B, H, q_hs)
+    Lfull[:, :, q_row0:q_row0 + nq] = Lb
+    dev = lambda t: t.cuda()
+    Qd, Kd, Vd, Od, Gd, Ld = dev(Qf), dev(Kf), dev(Vf), dev(Of), dev(Gf), dev(Lfull)
+    dQ = torch.full_like(Qd, float("nan"))
+    dK = torch.full_like(Kd, float("nan"))
+    dV = torch.full_like(Vd, float("nan"))
+    lib = _capi.lib()
+    need = lib.fa2_backward_workspace_bytes(B, H, q_hs, d, 0)
+    ws = torch.full((need,), 0xFF, dtype=torch.uint8, device="cuda")          # NaNs wherever phase 0 does not write
+    eb, off = 2, q_row0 * d
+    st = lib.fa2_backward_block(Qd.data_ptr() + off * eb, Kd.data_ptr(), Vd.data_ptr(), Od.data_ptr() + off * eb,
+                                Ld.data_ptr() + 4 * q_row0, Gd.data_ptr() + off * eb, dQ.data_ptr() + off * eb, dK.data_ptr(),
+                                dV.data_ptr(), B, H, nq, nk, d, s, 0, q_hs, k_hs, q_row0, 1 if causal else 0, shift,
+                                ws.data_ptr(), need, torch.cuda.current_stream().cuda_stream, 7)
+    assert st == 0
+    torch.cuda.synchronize()
+    for h in range(H):
+        sl = slice(q_row0, q_row0 + nq)
+        rq, rk, rv = _np_block_backward(f32(Qf[0, h, sl]), f32(Kf[0, h, :nk]), f32(Vf[0, h, :nk]), f32(Of[0, h, sl]),
+                                        Lb[0, h].numpy(), f32(Gf[0, h, sl]), s, causal, shift)
+        assert rel(f32(dQ[0, h, sl]), rq) <= BF16_REL
+        assert rel(f32(dK[0, h, :nk]), rk) <= BF16_REL
+        assert rel(f32(dV[0, h, :nk]), rv) <= BF16_REL
+        # rows / keys outside the block are not touched
+        assert torch.isnan(dQ[0, h, :q_row0].float()).all() and torch.isnan(dQ[0, h, q_row0 + nq:].float()).all()
+        assert torch.isnan(dK[0, h, nk:].float()).all() and torch.isnan(dV[0, h, nk:].float()).all()
 
 
 def test_dk_dv_full_head_medium():
@@ -336,7 +430,7 @@ def test_long_sequences_sampled_rows(dtype, N, causal, gate):
     """Maximum sizes: one head pair at the longest sequences BASELINE names, a strided sample of query rows
     against the oracle (a full pass would be hours of CPU), plus finiteness of everything."""
     fa, oracle = _fa(), _oracle()
-    B, H, d = 1, 2, 128
+    B, H, d = 1, 16, 128           # 16 heads: the XCD-aware block map of the bench (fa2_common.h: map_block), not its fallback
     dev = torch.device("cuda")
     g = torch.Generator(device=dev).manual_seed(5)
     td = torch.bfloat16 if dtype == "bf16" else torch.float8_e4m3fn
@@ -347,8 +441,8 @@ def test_long_sequences_sampled_rows(dtype, N, causal, gate):
     torch.cuda.synchronize()
     assert torch.isfinite(O.float()).all() and torch.isfinite(L).all()
     stride, off = N // 64, 37
-    h = 1
-    Or, Lr = oracle.attention_forward(f32(Q[0, h]), f32(K[0, h]), f32(V[0, h]), s, causal=causal, rows=(off, stride))
-    sel = np.arange(off, N, stride)
-    assert rel(f32(O[0, h])[sel], Or[sel]) <= gate
-    assert np.abs(L[0, h].cpu().numpy()[sel] - Lr[sel]).max() <= 1e-4
+    for h in (1, 14):
+        Or, Lr = oracle.attention_forward(f32(Q[0, h]), f32(K[0, h]), f32(V[0, h]), s, causal=causal, rows=(off, stride))
+        sel = np.arange(off, N, stride)
+        assert rel(f32(O[0, h])[sel], Or[sel]) <= gate
+        assert np.abs(L[0, h].cpu().numpy()[sel] - Lr[sel]).max() <= 1e-4

@@ -104,6 +104,24 @@ def test_accumulator_file_is_touched_by_asm_only(asm, file, pattern):
         assert any("v_mfma" in s for b in blocks for s in b)
 
 
+def test_dkdv_named_vgprs_are_the_bodies_own(asm):
+    """fa2_bwd_dkdv_kernel is compiled with amdgpu_num_vgpr(60): hipcc allocates v0..v59 only, v60..v255 belong to the
+    generated bodies (tools/gen_dkdv_body.py).  Nothing outside the asm regions may name them, and the descriptor
+    must cover the whole file (one wave per SIMD)."""
+    ks = {n: k for n, k in _kernels(asm["fa2_bwd_bf16"]).items() if "fa2_bwd_dkdv_kernel" in n}
+    assert len(ks) == 4
+    pat = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+    for name, k in ks.items():
+        outside, blocks = _split_asm(k["body"])
+        for s in outside:
+            for m in pat.finditer(s):
+                hi = int(m.group(1)) if m.group(1) else int(m.group(3))
+                assert hi < 60, (name, s)
+        assert k["meta"]["total"] == 512 and k["meta"]["agpr"] == 256, (name, k["meta"])
+        used = max(int(m.group(1) or m.group(3)) for b in blocks for s in b for m in pat.finditer(s))
+        assert used == (255 if "ILi128E" in name else 219), (name, used)      # VEND - 1 of tools/gen_dkdv_body.py
+
+
 def test_forward_loop_shape(asm):
     ks = _kernels(asm["fa2_fwd_bf16"])
     for D, mfmas in ((128, 96), (64, 48)):          # 3 tiles x 2 half-tile steps x (S^T: D/16 + O^T: D/16) MFMAs

@@ -97,7 +97,7 @@ def build(D, masked):
     ROWB = 2 * D
     SPB = 16 * ROWB
     NS = 4 * KS + 8 * DT
-    gA0, gA1, gB, gC, gD = 0, KS, 2 * KS, 4 * KS, 4 * KS + 4 * DT
+    gA0, gA1, gB, gC, gD = 0, KS + 1, 2 * KS, 4 * KS, 4 * KS + 4 * DT     # A0 holds KS + 1 MFMAs, A1 KS - 1
     mfma = [None] * NS
     tasks = []
 
@@ -121,29 +121,46 @@ def build(D, masked):
     # Two passes over the slot rotation so that 'free_after' of the first users refers to the previous body's consumers
     # (the schedule is cyclic): run the allocation once to learn the end state, then for real.
     def allocate(record):
+        # A0: k-step 0 of BOTH key blocks (S'[1] takes its start values -- the row constants -- from S'[0]'s registers as
+        # its C operand, before S'[0] is accumulated in place: one set of constant loads serves both), then S'[0] k-steps
+        # 1..KS-1; A1: S'[1] k-steps 1..KS-1 with the Q fragments read again.
+        slot, free = take_slot(1)
+        if record:
+            key = ("Q", 0, 0)
+            add_read(f"ds_read_b128 {R.slot(slot)}, %[r0] offset:@Q+0", key, 0, free)
+            mfma[0] = (f"v_mfma_f32_32x32x16_bf16 {R.sacc(1)}, {R.slot(slot)}, {R.kf(1, 0)}, {R.sacc(0)}", [key, ("RCS", 0)])
+            mfma[1] = (f"v_mfma_f32_32x32x16_bf16 {R.sacc(0)}, {R.slot(slot)}, {R.kf(0, 0)}, {R.sacc(0)}", [key])
         for kb in (0, 1):
-            for s in range(KS):
-                g = (gA0 if kb == 0 else gA1) + s
+            for s in range(1, KS):
+                g = (1 + s) if kb == 0 else (gA1 + s - 1)
                 slot, free = take_slot(g)
                 if record:
                     key = ("Q", kb, s)
                     add_read(f"ds_read_b128 {R.slot(slot)}, %[r{s}] offset:@Q+0", key, g, free)
-                    mfma[g] = (f"v_mfma_f32_32x32x16_bf16 {R.sacc(kb)}, {R.slot(slot)}, {R.kf(kb, s)}, {R.sacc(kb)}",
-                               [key] + ([("RCS", kb)] if s == 0 else []))
+                    mfma[g] = (f"v_mfma_f32_32x32x16_bf16 {R.sacc(kb)}, {R.slot(slot)}, {R.kf(kb, s)}, {R.sacc(kb)}", [key])
+        take_slot(gA1)                              # one slot number skipped: the rotation closes over a sub-tile
         for s in range(KS):
             g = gB + 2 * s
             sg, fg = take_slot(g + 1)
-            s0, f0 = take_slot(g)
-            s1, f1 = take_slot(g + 1)
+            if s == 0:                              # dP'[1] first: it starts from the constants in dP'[0]'s registers
+                s1, f1 = take_slot(g)
+                s0, f0 = take_slot(g + 1)
+            else:
+                s0, f0 = take_slot(g)
+                s1, f1 = take_slot(g + 1)
             if record:
                 kG, k0, k1 = ("G", s), ("V0", s), ("V1", s)
                 add_read(f"ds_read_b128 {R.slot(sg)}, %[r{s}] offset:@G+0", kG, g, fg)
-                add_read(f"ds_read_b128 {R.slot(s0)}, {R.roffv(s)}", k0, g, f0)
-                add_read(f"ds_read_b128 {R.slot(s1)}, {R.roffv(s)} offset:{32 * ROWB}", k1, g + 1, f1)
-                mfma[g] = (f"v_mfma_f32_32x32x16_bf16 {R.dpacc(0)}, {R.slot(sg)}, {R.slot(s0)}, {R.dpacc(0)}",
-                           [kG, k0] + ([("RCD", 0)] if s == 0 else []))
-                mfma[g + 1] = (f"v_mfma_f32_32x32x16_bf16 {R.dpacc(1)}, {R.slot(sg)}, {R.slot(s1)}, {R.dpacc(1)}",
-                               [kG, k1] + ([("RCD", 1)] if s == 0 else []))
+                if s == 0:
+                    add_read(f"ds_read_b128 {R.slot(s1)}, {R.roffv(s)} offset:{32 * ROWB}", k1, g, f1)
+                    add_read(f"ds_read_b128 {R.slot(s0)}, {R.roffv(s)}", k0, g + 1, f0)
+                    mfma[g] = (f"v_mfma_f32_32x32x16_bf16 {R.dpacc(1)}, {R.slot(sg)}, {R.slot(s1)}, {R.dpacc(0)}", [kG, k1, ("RCD", 0)])
+                    mfma[g + 1] = (f"v_mfma_f32_32x32x16_bf16 {R.dpacc(0)}, {R.slot(sg)}, {R.slot(s0)}, {R.dpacc(0)}", [kG, k0])
+                else:
+                    add_read(f"ds_read_b128 {R.slot(s0)}, {R.roffv(s)}", k0, g, f0)
+                    add_read(f"ds_read_b128 {R.slot(s1)}, {R.roffv(s)} offset:{32 * ROWB}", k1, g + 1, f1)
+                    mfma[g] = (f"v_mfma_f32_32x32x16_bf16 {R.dpacc(0)}, {R.slot(sg)}, {R.slot(s0)}, {R.dpacc(0)}", [kG, k0])
+                    mfma[g + 1] = (f"v_mfma_f32_32x32x16_bf16 {R.dpacc(1)}, {R.slot(sg)}, {R.slot(s1)}, {R.dpacc(1)}", [kG, k1])
         for nm, base, gs, acc, frag in (("GT", "@G", gC, R.dv, R.pf), ("QT", "@Q", gD, R.dk, R.dsf)):
             for sp in (0, 1):
                 for dt in range(DT):
@@ -172,7 +189,7 @@ def build(D, masked):
     last_p_read = {}        # (kb) -> last task reading the S'/P registers of kb      (the next row-constant load must follow it)
     last_d_read = {}
     for kb in (0, 1):
-        chain_end = (gA0 if kb == 0 else gA1) + KS - 1
+        chain_end = KS if kb == 0 else 2 * KS - 1
         rel_exp = chain_end + 3                  # the chain's last product has left the matrix pipe (> 12 wait states)
         exps = {}
         for sp in (0, 1):
@@ -210,23 +227,25 @@ def build(D, masked):
 
     # ---- row constants straight into the accumulator registers of the NEXT use (4 x b128 per tile: registers 4g..4g+3 are
     #      rows 8g + 4h ..).  They follow the last reader of those registers in issue order (`after`), in the previous body.
-    for kb in (0, 1):
-        consume = (gA0 if kb == 0 else gA1)
-        for g4 in range(4):
-            d0 = R.SACC + 16 * kb + 4 * g4
-            tasks.append(Task(f"ds_read_b128 v[{d0}:{d0 + 3}], %[rc] offset:@RC+{32 * g4}", COST["lds"], consume - READ_AHEAD - 4,
-                              consume - READ_LATEST, "lds", ("RCS", kb) if g4 == 3 else ("rcs", kb, g4), after=[("prev", last_p_read[kb])]))
-        consume = gB + kb
-        for g4 in range(4):
-            d0 = R.DPACC + 16 * kb + 4 * g4
-            tasks.append(Task(f"ds_read_b128 v[{d0}:{d0 + 3}], %[rc] offset:@RC+{256 + 32 * g4}", COST["lds"], consume - READ_AHEAD - 4,
-                              consume - READ_LATEST, "lds", ("RCD", kb) if g4 == 3 else ("rcd", kb, g4), after=[("prev", last_d_read[kb])]))
-    return R, mfma, tasks, NS
+    # The constants land in the kb = 0 tiles only (the kb = 1 chains take them from there as their C operand), but both tiles
+    # of a kind must have been read for the last time before: the first MFMA of the new chains overwrites the kb = 1 tile too.
+    for g4 in range(4):
+        d0 = R.SACC + 4 * g4
+        tasks.append(Task(f"ds_read_b128 v[{d0}:{d0 + 3}], %[rc] offset:@RC+{32 * g4}", COST["lds"], -READ_AHEAD - 4, -READ_LATEST, "lds",
+                          ("RCS", 0) if g4 == 3 else ("rcs", g4), after=[("prev", last_p_read[0])]))
+    for g4 in range(4):
+        d0 = R.DPACC + 4 * g4
+        tasks.append(Task(f"ds_read_b128 v[{d0}:{d0 + 3}], %[rc] offset:@RC+{256 + 32 * g4}", COST["lds"], gB - READ_AHEAD - 4,
+                          gB - READ_LATEST, "lds", ("RCD", 0) if g4 == 3 else ("rcd", g4), after=[("prev", last_d_read[0])]))
+    # the first MFMAs of the next chains write the kb = 1 tiles: their last readers must precede them (they do by a wide
+    # margin -- checked here rather than assumed)
+    guard_after = [(0, last_p_read[1]), (gB, last_d_read[1])]
+    return R, mfma, tasks, NS, guard_after
 
 
 def schedule(D, masked):
     """Places every task into a gap (possibly negative = previous body).  Returns per-gap lists in issue order."""
-    R, mfma, tasks, NS = build(D, masked)
+    R, mfma, tasks, NS, guard_after = build(D, masked)
     load = {}
     for i, t in enumerate(tasks):
         t.seq = i
@@ -264,6 +283,8 @@ def schedule(D, masked):
             pending.remove(t)
             progressed = True
         assert progressed, "dependency cycle"
+    for g_first, t in guard_after:
+        assert t.gap - NS < g_first - 2, (t.text, t.gap)
     per_gap = {}
     for t in tasks:
         per_gap.setdefault(t.gap, []).append(t)
@@ -285,6 +306,7 @@ def render(D, masked):
         return own, nxt
 
     issued = []         # keys in issue order; entries are (period, key)
+    waited_upto = [-1]  # index into `issued` up to which completion is known
     lines = []
     for period in (0, 1):
         for g in range(NS):
@@ -298,6 +320,11 @@ def render(D, masked):
                 if idx is not None:
                     pos = max(pos, idx)
             cnt = min(len(issued) - 1 - pos, 15) if pos >= 0 else None
+            # a wait is needed only if it asks for something an earlier wait has not already covered (LDS returns in order)
+            if cnt is not None and len(issued) - 1 - cnt <= waited_upto[0]:
+                cnt = None
+            if cnt is not None:
+                waited_upto[0] = len(issued) - 1 - cnt
             if period == 1:
                 if cnt is not None:
                     lines.append(f"s_waitcnt lgkmcnt({cnt})")
