@@ -88,22 +88,73 @@ constexpr int kDkQ = 32;        // query rows per sub-tile in kernel 2
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+#include "fa2_bwd_dq_body.inc"
+
+#define FA2_DQ_CLOBBERS "memory", "vcc", "v255", FA2_ACC_CLOBBERS
+#define FA2_DQ_OPS_128 [r0] "v"(roff[0]), [r1] "v"(roff[1]), [r2] "v"(roff[2]), [r3] "v"(roff[3]), [r4] "v"(roff[4]), [r5] "v"(roff[5]), \
+    [r6] "v"(roff[6]), [r7] "v"(roff[7]), [t0] "v"(toff[0]), [t1] "v"(toff[1]), [t2] "v"(toff[2]), [t3] "v"(toff[3]), [t4] "v"(toff[4]),     \
+    [t5] "v"(toff[5]), [t6] "v"(toff[6]), [t7] "v"(toff[7])
+#define FA2_DQ_OPS_64 [r0] "v"(roff[0]), [r1] "v"(roff[1]), [r2] "v"(roff[2]), [r3] "v"(roff[3]), [t0] "v"(toff[0]), [t1] "v"(toff[1]),    \
+    [t2] "v"(toff[2]), [t3] "v"(toff[3])
+
+// One literal VGPR move (see dkdv_vset below): seeds registers the generated bodies own.
+template <int R>
+__device__ __forceinline__ void dq_vset(float x)
+{
+    asm volatile("v_mov_b32 v%c1, %0" : : "v"(x), "i"(R) : "v255");
+}
+
+template <int D, int BUF, bool MASKED>
+__device__ __forceinline__ void dq_body(const uint32_t (&roff)[D / 16], const uint32_t (&toff)[D / 16], float c2, float lq0, float lq1,
+                                        const f32x16& nd0, const f32x16& nd1, int hi0, int hi1, int hp0, int hp1)
+{
+#define FA2_DQ_CASE(DD, B, M)                                                                                                      \
+    if constexpr (D == DD && BUF == B && MASKED == bool(M))                                                                          \
+        asm volatile(FA2_DQ_BODY_D##DD##_B##B##_M##M : : FA2_DQ_OPS_##DD, [c2] "s"(c2), [lq0] "v"(lq0), [lq1] "v"(lq1), [nd0] "v"(nd0), \
+                     [nd1] "v"(nd1), [hi0] "v"(hi0), [hi1] "v"(hi1), [hp0] "v"(hp0), [hp1] "v"(hp1) : FA2_DQ_CLOBBERS);
+    FA2_DQ_CASE(128, 0, 0) FA2_DQ_CASE(128, 1, 0) FA2_DQ_CASE(128, 2, 0) FA2_DQ_CASE(128, 0, 1) FA2_DQ_CASE(128, 1, 1) FA2_DQ_CASE(128, 2, 1)
+    FA2_DQ_CASE(64, 0, 0) FA2_DQ_CASE(64, 1, 0) FA2_DQ_CASE(64, 2, 0) FA2_DQ_CASE(64, 0, 1) FA2_DQ_CASE(64, 1, 1) FA2_DQ_CASE(64, 2, 1)
+#undef FA2_DQ_CASE
+}
+
+template <int D>
+__device__ __forceinline__ void dq_prologue(const uint32_t (&roff)[D / 16], const uint32_t (&toff)[D / 16], float c2, float lq0, float lq1)
+{
+    // the early work of the first tile: its first fragment reads, and the (harmless) VALU pass over the seeded SET1
+    const f32x16 z = {};
+    if constexpr (D == 128)
+        asm volatile(FA2_DQ_PRO_D128_M0 : : FA2_DQ_OPS_128, [c2] "s"(c2), [lq0] "v"(lq0), [lq1] "v"(lq1), [nd0] "v"(z), [nd1] "v"(z),
+                     [hi0] "v"(0), [hi1] "v"(0), [hp0] "v"(0), [hp1] "v"(0) : FA2_DQ_CLOBBERS);
+    else
+        asm volatile(FA2_DQ_PRO_D64_M0 : : FA2_DQ_OPS_64, [c2] "s"(c2), [lq0] "v"(lq0), [lq1] "v"(lq1), [nd0] "v"(z), [nd1] "v"(z),
+                     [hi0] "v"(0), [hi1] "v"(0), [hp0] "v"(0), [hp1] "v"(0) : FA2_DQ_CLOBBERS);
+}
+
+// The main loop is NOT scheduled by hipcc (as in kernel 2 below): amdgpu_num_vgpr(64) leaves v64..v255 and the whole
+// accumulator file to the generated bodies of fa2_bwd_dq_body.inc (tools/gen_dq_body.py: register map and schedule).
+// One body = one 64-key tile = 8 KS + 8 DT MFMAs; the two 32-key blocks of a tile are half a tile apart in a software
+// pipeline (S^T/dP^T of one block beside the exponentials, products and packs of the other), so the dQ^T products of
+// a tile's second block run in the NEXT body, against the K image that is still in the ring of three LDS buffers.
+// One barrier per tile, inside the body (vmcnt(0) + s_barrier in front of its first read of the next tile): every wave
+// past it has also finished with the tile before the previous one, so its buffer may take the next DMA.
 template <int D, bool CAUSAL>
-__global__ void __launch_bounds__(256, 1) fa2_bwd_dq_kernel(BwdArgs p)
+__global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(64))) fa2_bwd_dq_kernel(BwdArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWB = D * 2;
     constexpr int TILEB = kDqKV * ROWB;
-    constexpr int BUFB = 2 * TILEB;           // K tile | V tile
+    constexpr int VRING = 3 * TILEB;          // LDS: [3 K tiles][3 V tiles]; every offset from its address register < 64 KiB
     constexpr int CPR = D / 8;
     constexpr int RPI = 64 / CPR;
     constexpr int NP = kDqKV / RPI;           // DMA pieces per tensor per tile
     constexpr int KS = D / 16;
     constexpr int DT = D / 32;
-    // AGPR map
+    // AGPR map (the bodies use the same numbers)
     constexpr int A_DQ = 0;                   // dQ^T tile (qb, dt): a[A_DQ + (qb*DT + dt)*16 ..+15]
     constexpr int A_QF = 128;                 // Q fragment (qb, s): a[A_QF + (qb*KS + s)*4 ..+3]
     constexpr int A_GF = 192;                 // dO fragment (qb, s)
+    constexpr int SET1 = D == 128 ? FA2_DQ_D128_SET1 : FA2_DQ_D64_SET1;
+    constexpr int ROFFV = D == 128 ? FA2_DQ_D128_ROFFV : FA2_DQ_D64_ROFFV;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -131,7 +182,9 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dq_kernel(BwdArgs p)
         const int last_key = min(rb * kBwdRows + kBwdRows - 1, Nq - 1) + p.causal_shift;     // last visible key
         ntiles = min(ntiles, last_key < 0 ? 0 : last_key / kDqKV + 1);
     }
-    const int tend = (ntiles + 1) & ~1;       // whole pairs; a padding tile is fully masked
+    // whole triples of tiles (ring of three buffers: every LDS offset is an immediate) and at least one past the real ones,
+    // whose body finishes the second key block of the last real tile; the extra tiles are fully masked
+    const int niter = ((ntiles + 1 + 2) / 3) * 3;
 
     // ---- resident operands -> AGPRs; per-row constants
     int qrow[2];
@@ -159,6 +212,12 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dq_kernel(BwdArgs p)
     for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) negD[qb][r] = -Dq[qb];
+    // SET1 (S^T / dP^T of "key block 1 of the tile before the first"): P = exp2(-huge) = 0 and dP' = 0, so the first body's
+    // Q1 stage adds exactly zero
+    static_for<32>([&](auto R) {
+        dq_vset<SET1 + decltype(R)::value>(-1.0e30f);
+        dq_vset<SET1 + 32 + decltype(R)::value>(0.0f);
+    });
 
     // ---- LDS-DMA staging (as in fa2_fwd: one per-lane voffset, wave-uniform soffset, range-checked)
     const int drow = lane / CPR;
@@ -168,195 +227,66 @@ __global__ void __launch_bounds__(256, 1) fa2_bwd_dq_kernel(BwdArgs p)
     const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, N * ROWB, 0x00020000);
     const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, N * ROWB, 0x00020000);
     auto stage = [&](int t, int buf) {
-        char* b = smem + buf * BUFB;
+        char* b = smem + buf * TILEB;
 #pragma unroll
         for (int j = wave; j < 2 * NP; j += kDqWaves) {
             const int which = j / NP, piece = j % NP;
             const int soff = (t * kDqKV + piece * RPI) * ROWB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(which ? v_rsrc : k_rsrc, (lptr_t)(b + which * TILEB + piece * 1024),
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(which ? v_rsrc : k_rsrc, (lptr_t)(b + which * VRING + piece * 1024),
                                                      16, doff, soff, 0, 0);
         }
     };
-    if (tend > 0) stage(0, 0);
-    __syncthreads();
+    stage(0, 0);
+    stage(0, 2);          // the "previous" slot of the first body must hold finite data: tile 0 again
 
-    // ---- loop-invariant per-lane LDS offsets
+    // ---- loop-invariant per-lane LDS addresses (byte addresses; ring-buffer parts are immediates in the bodies)
+    const uint32_t lbase = (uint32_t)(uintptr_t)smem;
     const int trq = (lane & 15) >> 2;
     const int trp = lane & 3;
     const int trcb = (lane >> 4) & 1;
-    int roff[KS], toff[DT][2];
+    uint32_t roff[KS], toff[2 * DT];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) roff[s] = lds_off<D>(qi, 2 * s + h);            // +32 rows: kb = 1
+    for (int s = 0; s < KS; ++s) roff[s] = lbase + lds_off<D>(qi, 2 * s + h);            // +32 rows: kb = 1
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)      // +16 rows: sp = 1, +32 rows: kb = 1
-            toff[dt][jj] = lds_off<D>(8 * jj + 4 * h + trq, 4 * dt + 2 * trcb + (trp >> 1)) + 8 * (trp & 1);
-    const uint32_t lbase = (uint32_t)(uintptr_t)smem;
+            toff[2 * dt + jj] = lbase + lds_off<D>(8 * jj + 4 * h + trq, 4 * dt + 2 * trcb + (trp >> 1)) + 8 * (trp & 1);
 
-    // MASKED selects the variant that applies the key-tail / causal masks (a few tiles per
-    // workgroup); the common variant carries no mask arithmetic at all.
-#ifdef FA2_DIAG_STAMPS
-    unsigned long long diag_t0 = 0, diag_t1 = 0, diag_comp = 0, diag_sync = 0;
-#endif
-    auto tile_body = [&](auto BUF, auto MASKED_, int t) {
-        constexpr int buf = decltype(BUF)::value;
-        constexpr bool MASKED = decltype(MASKED_)::value;
-        constexpr int KB = buf * BUFB;
-        const char* Kt = smem + KB;
-        const char* Vt = Kt + TILEB;
-        if (t + 1 < tend) stage(t + 1, buf ^ 1);
-        const int key0 = t * kDqKV;
+    static_for<KS>([&](auto S) {               // row-read addresses of the V ring
+        constexpr int sidx = decltype(S)::value;
+        dq_vset<ROFFV + sidx>(__uint_as_float(roff[sidx] + VRING));
+    });
 
-        f32x16 sacc[2][2], dpacc[2][2];      // [qb][kb]: S^T[key][q], dP^T[key][q]
-
-        // dS of registers [r0, r0 + n) of key block kb, both row blocks, in place in dpacc:
-        // P = exp2(c S - L), dS = P dP'.  The chunk stays between the MFMA statements it is written
-        // between because those statements name the block's tiles as operands (fa2_common.h:
-        // mfma4_bagpr); the products it reads are at least four MFMA issues old by then, i.e. retired.
-        auto ds_chunk = [&](int kb, int r0, int n) {
-#pragma unroll
-            for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-                for (int r = r0; r < r0 + n; ++r) {
-                    float pr = __builtin_amdgcn_exp2f(sacc[qb][kb][r] * c2 - Lq[qb]);
-                    if constexpr (MASKED) {
-                        const int key = key0 + 32 * kb + acc_row(r, h);
-                        bool dead = key >= N;
-                        if (CAUSAL) dead = dead || key > qrow[qb] + p.causal_shift;
-                        if (dead) pr = 0.0f;
-                    }
-                    dpacc[qb][kb][r] = pr * dpacc[qb][kb][r];     // dP' already has -D in it
-                }
-        };
-
-        // ---- stage 1: S^T and dP^T, key block 0 then 1; the dS arithmetic of block 0 runs between
-        // the MFMA groups of block 1
-        constexpr int RP1 = 16 / KS;          // registers per row block handled beside one k-step
-        // K / V row fragments are read TWO k-steps ahead of their MFMAs: with one wave per SIMD an
-        // LDS round trip (> 100 cycles under load) is longer than one group of four MFMAs.
-        auto kfrag = [&](auto I_) {
-            constexpr int i = decltype(I_)::value;
-            return lds_read_frag(Kt, roff[i % KS] + (i / KS) * 32 * ROWB);
-        };
-        auto vfrag = [&](auto I_) {
-            constexpr int i = decltype(I_)::value;
-            return lds_read_frag(Vt, roff[i % KS] + (i / KS) * 32 * ROWB);
-        };
-        bf16x8 ka = kfrag(std::integral_constant<int, 0>{}), va = vfrag(std::integral_constant<int, 0>{});
-        bf16x8 kb1 = kfrag(std::integral_constant<int, 1>{}), vb1 = vfrag(std::integral_constant<int, 1>{});
-        static_for<2 * KS>([&](auto I) {
-            constexpr int i = decltype(I)::value;
-            constexpr int kb = i / KS, sidx = i % KS;
-            bf16x8 kn = kb1, vn = vb1;
-            if constexpr (i + 2 < 2 * KS) {
-                kn = kfrag(std::integral_constant<int, i + 2>{});
-                vn = vfrag(std::integral_constant<int, i + 2>{});
-            }
-            if constexpr (sidx == 0)
-                mfma4_bagpr_init<A_QF + (0 * KS + sidx) * 4, A_QF + (1 * KS + sidx) * 4, A_GF + (0 * KS + sidx) * 4,
-                                 A_GF + (1 * KS + sidx) * 4>(sacc[0][kb], sacc[1][kb], dpacc[0][kb], dpacc[1][kb], ka, va,
-                                                             negD[0], negD[1]);
-            else if constexpr (kb == 1)
-                mfma4_bagpr<A_QF + (0 * KS + sidx) * 4, A_QF + (1 * KS + sidx) * 4, A_GF + (0 * KS + sidx) * 4,
-                            A_GF + (1 * KS + sidx) * 4>(sacc[0][1], sacc[1][1], dpacc[0][1], dpacc[1][1], ka, va,
-                                                        sacc[0][0], sacc[1][0], dpacc[0][0], dpacc[1][0]);
-            else
-                mfma4_bagpr<A_QF + (0 * KS + sidx) * 4, A_QF + (1 * KS + sidx) * 4, A_GF + (0 * KS + sidx) * 4,
-                            A_GF + (1 * KS + sidx) * 4>(sacc[0][kb], sacc[1][kb], dpacc[0][kb], dpacc[1][kb], ka, va);
-            if constexpr (kb == 1 && sidx == 0) thread4(sacc[0][0], sacc[1][0], dpacc[0][0], dpacc[1][0]);
-            if constexpr (kb == 1) {
-                ds_chunk(0, sidx * RP1, RP1);
-                keep_alive(ka); keep_alive(va);
-            }
-            ka = kb1; va = vb1; kb1 = kn; vb1 = vn;
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        bf16x8 dsf[2][2][2];                   // [qb][kb][sp]
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            dsf[qb][0][0] = pack_acc(dpacc[qb][0], 0);
-            dsf[qb][0][1] = pack_acc(dpacc[qb][0], 1);
-        }
-        // K^T fragments are read two groups ahead; the block-1 products get time to retire meanwhile
-        auto tfrag = [&](auto G_, bf16x4& r0, bf16x4& r1) {
-            constexpr int g = decltype(G_)::value;
-            constexpr int kbn = g / (2 * DT), dtn = (g % (2 * DT)) >> 1, spn = g & 1;
-            lds_read_tr2_asm<KB + kbn * 32 * ROWB + spn * 16 * ROWB>(r0, r1, lbase + toff[dtn][0], lbase + toff[dtn][1]);
-        };
-        bf16x4 ta0, ta1, tb0, tb1;
-        tfrag(std::integral_constant<int, 0>{}, ta0, ta1);
-        tfrag(std::integral_constant<int, 1>{}, tb0, tb1);
-        mfma_vgpr_settle(sacc[1][1]);
-        __builtin_amdgcn_sched_barrier(0);
-
-        // ---- stage 2: dQ^T[dcol][q] += K^T[dcol][key] dS^T[key][q], group g = (kb, dt, sp); the dS
-        // arithmetic of block 1 runs between the groups of block 0
-        constexpr int RP2 = 16 / (2 * DT);
-        static_for<4 * DT>([&](auto G) {
-            constexpr int g = decltype(G)::value;
-            constexpr int kb = g / (2 * DT), dt = (g % (2 * DT)) >> 1, sp = g & 1;
-            bf16x4 tn0 = tb0, tn1 = tb1;
-            if constexpr (g + 2 < 4 * DT) {
-                tfrag(std::integral_constant<int, g + 2>{}, tn0, tn1);
-                lds_tr_wait2<4>(ta0, ta1);          // groups g+1 and g+2 may still be in flight
-            } else if constexpr (g + 1 < 4 * DT) {
-                lds_tr_wait2<2>(ta0, ta1);
-            } else {
-                lds_tr_wait2<0>(ta0, ta1);
-            }
-            bf16x8 kT;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { kT[e] = ta0[e]; kT[4 + e] = ta1[e]; }
-            if constexpr (kb == 0)
-                acc_mfma2<A_DQ + (0 * DT + dt) * 16, A_DQ + (1 * DT + dt) * 16>(kT, dsf[0][kb][sp], dsf[1][kb][sp],
-                                                                                sacc[0][1], sacc[1][1], dpacc[0][1], dpacc[1][1]);
-            else
-                acc_mfma2<A_DQ + (0 * DT + dt) * 16, A_DQ + (1 * DT + dt) * 16>(kT, dsf[0][kb][sp], dsf[1][kb][sp]);
-            if constexpr (kb == 0) {
-                ds_chunk(1, (g % (2 * DT)) * RP2, RP2);
-                keep_alive(kT);
-                if constexpr (g == 2 * DT - 1) {
-#pragma unroll
-                    for (int qb = 0; qb < 2; ++qb) {
-                        dsf[qb][1][0] = pack_acc(dpacc[qb][1], 0);
-                        dsf[qb][1][1] = pack_acc(dpacc[qb][1], 1);
-                    }
-                }
-            }
-            ta0 = tb0; ta1 = tb1; tb0 = tn0; tb1 = tn1;
-            __builtin_amdgcn_sched_barrier(0);
-        });
-#ifdef FA2_DIAG_STAMPS
-        { unsigned long long ts; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts) :: "memory"); diag_t1 = ts; }
-#endif
-        __syncthreads();     // drains this wave's DMA (vmcnt) and hands the buffers over
-#ifdef FA2_DIAG_STAMPS
-        { unsigned long long ts; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts) :: "memory");
-          diag_sync += ts - diag_t1; diag_comp += diag_t1 - diag_t0; diag_t0 = ts; }
-#endif
-    };
+    __syncthreads();                         // tile 0 has landed (vmcnt(0) inside)
+    dq_prologue<D>(roff, toff, c2, Lq[0], Lq[1]);
 
     auto tile = [&](auto BUF, int t) {
+        constexpr int buf = decltype(BUF)::value;
+        stage(t + 1, (buf + 1) % 3);         // its buffer was last read two bodies ago, before that body's barrier
         const int key0 = t * kDqKV;
+        // this body holds the arithmetic of tile t's first key block and of tile t-1's second one
         bool masked = key0 + kDqKV > N;
         if (CAUSAL) masked = masked || key0 + kDqKV - 1 > q0 + p.causal_shift;
-        if (masked) tile_body(BUF, std::true_type{}, t);
-        else tile_body(BUF, std::false_type{}, t);
-    };
-#ifdef FA2_DIAG_STAMPS
-    { unsigned long long ts; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts) :: "memory"); diag_t0 = ts; }
+#ifdef FA2_DQ_FORCE_MASKED
+        masked = true;                       // diagnostic build: every tile through the masked bodies
 #endif
-    for (int t = 0; t < tend; t += 2) {
+        if (masked) {                        // wave-uniform and rare
+            int hi[2];
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+                hi[qb] = (CAUSAL ? min(N, qrow[qb] + p.causal_shift + 1) : N) - key0 - 4 * h;
+            dq_body<D, buf, true>(roff, toff, c2, Lq[0], Lq[1], negD[0], negD[1], hi[0], hi[1], hi[0] + kDqKV, hi[1] + kDqKV);
+        } else {
+            dq_body<D, buf, false>(roff, toff, c2, Lq[0], Lq[1], negD[0], negD[1], 0, 0, 0, 0);
+        }
+    };
+    for (int t = 0; t < niter; t += 3) {
         tile(std::integral_constant<int, 0>{}, t);
         tile(std::integral_constant<int, 1>{}, t + 1);
+        tile(std::integral_constant<int, 2>{}, t + 2);
     }
-#ifdef FA2_DIAG_STAMPS
-    if (lane == 0) {      // diagnostic build only: cycle sums go to the row-constant workspace, which nothing else reads here
-        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.RC) + ((size_t)blockIdx.x * kDqWaves + wave) * 2;
-        dbg[0] = diag_comp; dbg[1] = diag_sync;
-    }
-#endif
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // the last body's look-ahead DMA and reads
 
     mfma_acc_settle();
     static_for<2>([&](auto QB) {
@@ -621,7 +551,7 @@ static hipError_t launch_bwd_one(const BwdArgs& a, hipStream_t stream)
         if (e != hipSuccess) return e;
     }
     const int nb = (a.Nq + kBwdRows - 1) / kBwdRows;
-    constexpr int lds_dq = 2 * 2 * kDqKV * D * 2;
+    constexpr int lds_dq = 3 * 2 * kDqKV * D * 2;      // ring of three (K tile | V tile)
     constexpr int lds_dk = kDkKeys * D * 2 + 2 * (2 * 2 * kDkQ * D * 2 + 512);
     static bool set_dq[64] = {}, set_dk[64] = {};
     e = ensure_dynamic_lds(fa2_bwd_dq_kernel<D, CAUSAL>, lds_dq, set_dq);

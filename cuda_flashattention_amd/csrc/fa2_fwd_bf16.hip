@@ -438,6 +438,14 @@ __global__ void __launch_bounds__(64 * kFwdWaves, 1) fa2_fwd_bf16_kernel(FwdArgs
         for (int jj = 0; jj < 2; ++jj)      // V region base folded in; +16 rows: sp = 1
             va[dt][jj] = lbase + VREG + lds_off<D>(8 * jj + 4 * h + trq, 4 * dt + 2 * trcb + (trp >> 1)) + 8 * (trp & 1);
 
+    // Two waves share each SIMD; the second-dispatched half of the workgroup (waves 4-7) loses every VALU arbitration to
+    // the older half (priority, then age).  One static priority bump for that half, and no per-stage flips, removes its
+    // start-of-stage penalty (MI355X_MICROARCH.md, 'Two waves per SIMD' item 4).  `wave` is wave-uniform by construction
+    // (readfirstlane), so this is a scalar branch around one s_setprio.
+#ifndef FA2_NO_SETPRIO
+    if (wave >= kFwdWaves / 2) __builtin_amdgcn_s_setprio(1);
+#endif
+
     // ---- pipeline registers
     f32x16 scur;             // S^T of half-tile u     (keys on registers, query on the lane)
     bf16x8 pprev[2];         // packed P of half-tile u-1, per k-step

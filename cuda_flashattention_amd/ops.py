@@ -90,8 +90,9 @@ def flash_attention_2_backward(Q, K, V, O, L, dO, softmax_scale=None, causal=Fal
     (reference 02_backward/flash_attention_backward_kernel.cu:249-262).  dO must be contiguous (autograd often hands
     over an expanded or transposed view: call .contiguous() on it first -- the C ABI reads a dense tensor)."""
     B, H, N, d = shape = _bhnd(Q, "Q")
-    for n, t in (("K", K), ("V", V), ("O", O), ("dO", dO)):
-        _like(t, n, Q, shape, Q.dtype)
+    gdt = torch.bfloat16 if Q.dtype == torch.float8_e4m3fn else Q.dtype       # what the forward produced for fp8 inputs
+    for n, t, dt in (("K", K, Q.dtype), ("V", V, Q.dtype), ("O", O, gdt), ("dO", dO, gdt)):
+        _like(t, n, Q, shape, dt)
     _rows(L, "L", Q, B, H, N)
     scale = float(softmax_scale) if softmax_scale is not None else 1.0 / math.sqrt(d)
     dQ = torch.empty_like(Q) if dQ is None else _like(dQ, "dQ", Q, shape, Q.dtype)

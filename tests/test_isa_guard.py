@@ -104,11 +104,12 @@ def test_accumulator_file_is_touched_by_asm_only(asm, file, pattern):
         assert any("v_mfma" in s for b in blocks for s in b)
 
 
-def test_dkdv_named_vgprs_are_the_bodies_own(asm):
-    """fa2_bwd_dkdv_kernel is compiled with amdgpu_num_vgpr(60): hipcc allocates v0..v59 only, v60..v255 belong to the
-    generated bodies (tools/gen_dkdv_body.py).  Nothing outside the asm regions may name them, and the descriptor
-    must cover the whole file (one wave per SIMD)."""
-    ks = {n: k for n, k in _kernels(asm["fa2_bwd_bf16"]).items() if "fa2_bwd_dkdv_kernel" in n}
+@pytest.mark.parametrize("pattern,limit,top128,top64", [("fa2_bwd_dkdv_kernel", 60, 255, 219), ("fa2_bwd_dq_kernel", 64, 255, 251)])
+def test_named_vgprs_are_the_bodies_own(asm, pattern, limit, top128, top64):
+    """The backward kernels are compiled with amdgpu_num_vgpr(60 / 64): hipcc allocates the low registers only, the rest
+    belong to the generated bodies (tools/gen_dkdv_body.py, tools/gen_dq_body.py).  Nothing outside the asm regions may
+    name them, and the descriptor must cover the whole file (one wave per SIMD)."""
+    ks = {n: k for n, k in _kernels(asm["fa2_bwd_bf16"]).items() if pattern in n}
     assert len(ks) == 4
     pat = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
     for name, k in ks.items():
@@ -116,10 +117,10 @@ def test_dkdv_named_vgprs_are_the_bodies_own(asm):
         for s in outside:
             for m in pat.finditer(s):
                 hi = int(m.group(1)) if m.group(1) else int(m.group(3))
-                assert hi < 60, (name, s)
+                assert hi < limit, (name, s)
         assert k["meta"]["total"] == 512 and k["meta"]["agpr"] == 256, (name, k["meta"])
         used = max(int(m.group(1) or m.group(3)) for b in blocks for s in b for m in pat.finditer(s))
-        assert used == (255 if "ILi128E" in name else 219), (name, used)      # VEND - 1 of tools/gen_dkdv_body.py
+        assert used == (top128 if "ILi128E" in name else top64), (name, used)      # VEND - 1 of the generator
 
 
 def test_forward_loop_shape(asm):
@@ -148,7 +149,7 @@ def test_backward_loop_shape(asm):
             # masked variant of each tile is a second copy of the body
             per_tile = 8 * ksteps + 8 * dts
             n = sum("v_mfma_f32_32x32x16_bf16" in l for l in _main_loop(ks[dq]["body"]))
-            assert n % per_tile == 0 and 2 <= n // per_tile <= 4, (dq, n)
+            assert n == 6 * per_tile, (dq, n)          # ring of three tiles, plain and masked bodies
             dk = next(n for n in ks if f"fa2_bwd_dkdv_kernelILi{D}ELb{causal}E" in n)
             # per 32-row sub-tile and wave: S', dP' 2 x ksteps each, dV^T, dK^T 2 x 2 x dts each (generated bodies)
             per_sub = 4 * ksteps + 8 * dts
@@ -162,6 +163,32 @@ def test_fp8_loop_budget(asm):
         if "fa2_fwd_fp8_kernel" in name:
             assert k["meta"]["agpr"] <= 128 and k["meta"]["total"] <= 256, (name, k["meta"])
             assert any("v_mfma_f32_32x32x64_f8f6f4" in l for l in _main_loop(k["body"]))
+
+
+@pytest.mark.parametrize("inc", ["fa2_bwd_dkdv_body.inc", "fa2_bwd_dq_body.inc"])
+def test_generated_bodies_pass_the_static_checker(inc):
+    """tools/check_body.py replays every generated main-loop body twice in a row (steady state) with an in-order model of
+    the LDS queue: each MFMA source delivered by an LDS read is covered by a counted lgkmcnt, no read overwrites a
+    fragment before its consumers have issued, no VALU instruction touches an MFMA result too early or a register an LDS
+    read is still writing, and no MFMA reads a register a VALU instruction wrote the instruction before."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_body", os.path.join(ROOT, "tools", "check_body.py"))
+    cb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cb)
+    text = open(os.path.join(CSRC, inc)).read()
+    names = re.findall(r"#define (FA2_\w+_BODY_\w+) ", text)
+    assert len(names) in (12, 16)
+    for n in names:
+        assert cb.check(cb.body(text, n), n) == []
+
+
+def test_generated_bodies_are_up_to_date(tmp_path):
+    """The committed .inc files are what the generators produce (nobody edits them by hand, nobody forgets to regenerate)."""
+    for gen, inc in (("gen_dkdv_body.py", "fa2_bwd_dkdv_body.inc"), ("gen_dq_body.py", "fa2_bwd_dq_body.inc")):
+        out = tmp_path / inc
+        subprocess.check_call(["python3", os.path.join(ROOT, "tools", gen), "--out", str(out)], cwd=os.path.join(ROOT, "tools"),
+                              stdout=subprocess.DEVNULL)
+        assert out.read_text() == open(os.path.join(CSRC, inc)).read(), inc
 
 
 def test_version_names_the_compiler():

@@ -232,74 +232,87 @@ def build(D, masked):
     for g4 in range(4):
         d0 = R.SACC + 4 * g4
         tasks.append(Task(f"ds_read_b128 v[{d0}:{d0 + 3}], %[rc] offset:@RC+{32 * g4}", COST["lds"], -READ_AHEAD - 4, -READ_LATEST, "lds",
-                          ("RCS", 0) if g4 == 3 else ("rcs", g4), after=[("prev", last_p_read[0])]))
+                          ("RCS", 0) if g4 == 3 else ("rcs", g4)))
+        tasks[-1].release = max(tasks[-1].release, max(last_p_read[0].deadline, last_p_read[1].deadline) - NS + 1)
+        tasks[-1].deadline = max(tasks[-1].deadline, tasks[-1].release)
     for g4 in range(4):
         d0 = R.DPACC + 4 * g4
         tasks.append(Task(f"ds_read_b128 v[{d0}:{d0 + 3}], %[rc] offset:@RC+{256 + 32 * g4}", COST["lds"], gB - READ_AHEAD - 4,
-                          gB - READ_LATEST, "lds", ("RCD", 0) if g4 == 3 else ("rcd", g4), after=[("prev", last_d_read[0])]))
+                          gB - READ_LATEST, "lds", ("RCD", 0) if g4 == 3 else ("rcd", g4)))
+        tasks[-1].release = max(tasks[-1].release, max(last_d_read[0].deadline, last_d_read[1].deadline) - NS + 1)
+        tasks[-1].deadline = max(tasks[-1].deadline, tasks[-1].release)
     # the first MFMAs of the next chains write the kb = 1 tiles: their last readers must precede them (they do by a wide
     # margin -- checked here rather than assumed)
     guard_after = [(0, last_p_read[1]), (gB, last_d_read[1])]
     return R, mfma, tasks, NS, guard_after
 
 
-def schedule(D, masked):
-    """Places every task into a gap (possibly negative = previous body).  Returns per-gap lists in issue order."""
-    R, mfma, tasks, NS, guard_after = build(D, masked)
+def place(tasks, NS, budget=None):
+    """Places every task into a gap (possibly negative = previous body), earliest deadline first, respecting the
+    dependencies in `after`.  Returns (per-gap lists in issue order, per-gap load)."""
+    budget = GAP_BUDGET if budget is None else budget
     load = {}
     for i, t in enumerate(tasks):
         t.seq = i
-    order = sorted(tasks, key=lambda t: (t.deadline, t.seq))
-    done = set()
-    pending = list(order)
-    guard = 0
-    while pending:
-        guard += 1
-        assert guard < 100000
-        progressed = False
-        for t in list(pending):
-            lo = t.release
-            ok = True
-            for dep in t.after:
-                if isinstance(dep, tuple):           # ("prev", task): the dependency sits in the PREVIOUS body
-                    d = dep[1]
-                    if d.gap is None:
-                        ok = False
-                        break
-                    lo = max(lo, d.gap - NS + 1)
-                else:
-                    if dep.gap is None:
-                        ok = False
-                        break
-                    lo = max(lo, dep.gap + (1 if dep.kind == "exp" else 0))    # a trans result is not read in the same gap
-            if not ok:
-                continue
-            g = lo
-            while load.get(g % NS, 0) + t.cost > GAP_BUDGET and g < t.deadline:
-                g += 1
-            assert g <= t.deadline, (t.text, g, t.deadline)
-            t.gap = g
-            load[g % NS] = load.get(g % NS, 0) + t.cost
-            pending.remove(t)
-            progressed = True
-        assert progressed, "dependency cycle"
-    for g_first, t in guard_after:
-        assert t.gap - NS < g_first - 2, (t.text, t.gap)
+    # LDS reads are placed FIRST, on their own: which of them a body leaves in flight for the next one (the tasks with
+    # negative gaps) must not depend on the VALU load, because plain and masked bodies follow each other in any order.
+    for phase in (0, 1):
+        pending = sorted((t for t in tasks if (t.kind == "lds") == (phase == 0)), key=lambda t: (t.deadline, t.seq))
+        guard = 0
+        while pending:
+            guard += 1
+            assert guard < 100000
+            progressed = False
+            for t in list(pending):
+                lo = t.release
+                ok = True
+                for dep in t.after:
+                    if isinstance(dep, tuple):           # ("prev", task): the dependency sits in the PREVIOUS body
+                        d = dep[1]
+                        if d.gap is None:
+                            ok = False
+                            break
+                        lo = max(lo, d.gap - NS + 1)
+                    else:
+                        if dep.gap is None:
+                            ok = False
+                            break
+                        lo = max(lo, dep.gap + (1 if dep.kind == "exp" else 0))    # a trans result is not read in the same gap
+                if not ok:
+                    continue
+                g = lo
+                while load.get(g % NS, 0) + t.cost > budget and g < t.deadline:
+                    g += 1
+                assert g <= t.deadline, (t.text, g, t.deadline)
+                t.gap = g
+                load[g % NS] = load.get(g % NS, 0) + t.cost
+                pending.remove(t)
+                progressed = True
+            assert progressed, "dependency cycle (an LDS task may not depend on a VALU task)"
     per_gap = {}
     for t in tasks:
         per_gap.setdefault(t.gap, []).append(t)
     for g in per_gap:
         per_gap[g].sort(key=lambda t: (0 if t.kind == "lds" else 1, t.seq))
-    return R, mfma, tasks, per_gap, [load.get(g, 0) for g in range(NS)], NS
+    return per_gap, [load.get(g, 0) for g in range(NS)]
 
 
-def render(D, masked):
-    """(body lines with @placeholders, prologue lines).  Lines tagged '@N ' use the NEXT sub-tile's bases."""
-    R, mfma, tasks, per_gap, load, NS = schedule(D, masked)
+def schedule(D, masked):
+    R, mfma, tasks, NS, guard_after = build(D, masked)
+    per_gap, load = place(tasks, NS)
+    for g_first, t in guard_after:
+        assert t.gap - NS < g_first - 2, (t.text, t.gap)
+    assert all(t.kind == "lds" for t in tasks if t.gap < 0)
+    return R, mfma, tasks, per_gap, load, NS
+
+
+def render_lines(mfma, per_gap, NS):
+    """(body lines with @placeholders, prologue lines) of a cyclic schedule.  Lines tagged '@N ' belong to the NEXT
+    body's early work (they use the next unit's bases); the counted lgkmcnt in front of each MFMA is derived from the
+    steady-state issue order of the LDS operations (two periods are simulated, the second one is emitted)."""
     gmin = min(per_gap)
     assert gmin >= -NS, gmin
-    # steady-state issue order of LDS operations over one period, to derive the counted waits: simulate two periods
-    # of (own gaps 0..NS-1, with the wrapped tasks of the next body falling into gaps NS+gap).
+
     def gap_items(g):
         own = per_gap.get(g, []) if g >= 0 else []
         nxt = per_gap.get(g - NS, []) if g - NS < 0 else []
@@ -311,8 +324,6 @@ def render(D, masked):
     for period in (0, 1):
         for g in range(NS):
             text, needs = mfma[g]
-            # find the needed keys among issued: own keys carry `period` if issued at gap >= 0 of this period, or were issued as
-            # 'next' tasks during the previous period (tagged with period too)
             pos = -1
             for k in needs:
                 idx = max(i for i, (p, kk) in enumerate(issued) if kk == k and p == period) if any(kk == k and p == period for p, kk in issued) else None
@@ -345,6 +356,12 @@ def render(D, masked):
     for g in range(NS):
         for t in per_gap.get(g - NS, []):
             pro.append("@N " + t.text)
+    return lines, pro
+
+
+def render(D, masked):
+    R, mfma, tasks, per_gap, load, NS = schedule(D, masked)
+    lines, pro = render_lines(mfma, per_gap, NS)
     return R, lines, pro, load, NS
 
 
@@ -390,6 +407,7 @@ def main():
               "// reads of the very first sub-tile).  Register map and schedule: tools/gen_dkdv_body.py.\n"]
     for D in (128, 64):
         R0 = Regs(D)
+        assert sorted(render(D, False)[2]) == sorted(render(D, True)[2]), "plain and masked bodies must leave the same reads in flight"
         chunks.append(f"#define FA2_DKDV_D{D}_KF {R0.KF}\n#define FA2_DKDV_D{D}_ROFFV {R0.ROFFV}\n#define FA2_DKDV_D{D}_VEND {R0.VEND}\n"
                       f"#define FA2_DKDV_D{D}_A_DK {R0.A_DK}\n#define FA2_DKDV_D{D}_A_DV {R0.A_DV}\n")
         for masked in (0, 1):
@@ -400,6 +418,7 @@ def main():
                       f"{sum(l > GAP_BUDGET for l in load)} of {NS} gaps over {GAP_BUDGET}")
                 print("   load:", " ".join(f"{l}" for l in load))
             p = resolve(pro, D, 1, 1, False)          # 'next' of (buffer 1, sub-tile 1) is (buffer 0, sub-tile 0): the first one
+            p.append("s_waitcnt lgkmcnt(0)")          # in steady state the previous body's last waits cover these reads
             chunks.append(f"#define FA2_DKDV_PRO_D{D}_M{masked} \\\n" + c_string(p) + "\n")
             for buf in (0, 1):
                 for sh in (0, 1):
