@@ -226,6 +226,25 @@ def main():
                 return {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1), "timing": "median of 3 x 20 launches after 50 warm-up launches"}
             extra["fwd_bf16_cfg2_(4,16,4096,64)"] = fwd_only(4, 16, 4096, 64, torch.bfloat16, False)
             extra["fwd_fp8_e4m3_causal_cfg5_(1,16,32768,128)"] = fwd_only(1, 16, 32768, 128, torch.float8_e4m3fn, True)
+            # the reference's FlashAttention-1 step restated (scalar fp32, one head, no MFMA): a DIDACTIC row, not a target
+            Nf, df = 4096, 64
+            qf, kf, vf = (torch.rand(Nf, df, device=dev) - 0.5 for _ in range(3))
+            of = torch.empty(Nf, df, device=dev)
+            lf, mf = torch.empty(Nf, device=dev), torch.empty(Nf, device=dev)
+            lib = fa._capi.lib()
+            f1 = lambda: lib.flash_attention(qf.data_ptr(), kf.data_ptr(), vf.data_ptr(), of.data_ptr(), lf.data_ptr(), mf.data_ptr(),
+                                             Nf, df, 32, 1024)
+            torch.cuda.synchronize()          # flash_attention runs on the default stream, like the reference's
+            for _ in range(3):
+                f1()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                f1()
+            torch.cuda.synchronize()
+            msf = (time.perf_counter() - t0) / 5 * 1e3
+            extra["fa1_didactic_fp32_(1,1,4096,64)"] = {"ms": round(msf, 4), "tflops": round(4.0 * Nf * Nf * df / msf / 1e9, 3),
+                                                        "note": "01_flash_attention_v1 restated: one thread per query row, fp32 FMAs"}
             out["side_figures"] = extra
         except Exception as e:
             out["side_figures"] = {"error": repr(e)}

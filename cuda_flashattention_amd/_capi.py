@@ -28,6 +28,7 @@ _sz = ctypes.c_size_t
 SIGNATURES = {
     "fa2_version": (ctypes.c_char_p, []),
     "fa2_status_string": (ctypes.c_char_p, [_i]),
+    "flash_attention": (_i, [_vp] * 6 + [_i, _i, _i, _i]),
     "flash_attention_2_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f]),
     "flash_attention_2_backward": (_i, [_vp] * 9 + [_i, _i, _f]),
     "fa2_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp]),

@@ -288,6 +288,15 @@ int flash_attention_2_forward(const float* Q, const float* K, const float* V,
     return fa2_forward(Q, K, V, O, L, 1, 1, seq_len, head_dim, softmax_scale, FA2_DTYPE_F32, 0, nullptr);
 }
 
+int flash_attention(const float* Q, const float* K, const float* V, float* O, float* l, float* m, int N, int d, int Bc, int M)
+{
+    (void)Bc; (void)M;
+    if (!Q || !K || !V || !O || !l || !m) return FA2_ERR_NULL_POINTER;
+    if (N <= 0 || d <= 0) return FA2_ERR_INVALID_SHAPE;
+    if (d > 128) return FA2_ERR_UNSUPPORTED_HEAD_DIM;
+    return hip_status(fa2::launch_fa1_f32(Q, K, V, O, l, m, N, d, nullptr));
+}
+
 int flash_attention_2_backward(const float* Q, const float* K, const float* V,
                                const float* O, const float* L, const float* dO,
                                float* dQ, float* dK, float* dV,

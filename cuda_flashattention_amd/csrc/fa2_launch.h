@@ -100,6 +100,10 @@ inline hipError_t ensure_dynamic_lds(Kern kern, int bytes, bool (&done)[64])
     return hipSuccess;
 }
 
+// FlashAttention-1 restatement (fa1_f32.hip): one head, fp32, didactic baseline row.
+hipError_t launch_fa1_f32(const float* Q, const float* K, const float* V, float* O, float* l, float* m, int N, int d,
+                          hipStream_t stream);
+
 // Element-wise helpers (fa2_util.hip).
 hipError_t launch_fill_f32(float* p, size_t n, float value, hipStream_t stream);
 hipError_t launch_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t stream);

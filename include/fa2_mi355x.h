@@ -71,6 +71,13 @@ int flash_attention_2_backward(const float* Q, const float* K, const float* V,
                                float* dQ, float* dK, float* dV,
                                int seq_len, int head_dim, float softmax_scale);
 
+/* replaces flash_attention (01_flash_attention_v1/main.cu:7-20), the FlashAttention-1 step of the reference's staircase:
+ * O = softmax(Q K^T / sqrt(d)) V for one fp32 head with the running row sums l and row maxima m written beside it
+ * (m + ln l is the row's log-sum-exp).  Bc and M are accepted for signature compatibility and ignored (the reference
+ * uses them to size its tiles).  A didactic baseline (scalar fp32, no MFMA): the fast path is flash_attention_2_forward. */
+int flash_attention(const float* Q, const float* K, const float* V, float* O, float* l, float* m,
+                    int N, int d, int Bc, int M);
+
 /* ======================================================================================
  * Extended entry points: (B, H), dtype, causal mask, stream.
  * ==================================================================================== */

@@ -143,3 +143,51 @@ def test_fa1_literal_cases_through_the_dropin(golden):
                                             torch.from_numpy(V).cuda(), 1.0 / np.sqrt(d))
         torch.cuda.synchronize()
         assert np.abs(O.cpu().numpy() - Oref).max() <= 1e-3, name
+
+
+def test_fa1_baseline_reference_cases(golden):
+    """flash_attention (the FlashAttention-1 step, 01_flash_attention_v1/main.cu:7-20): the reference's own literal test
+    cases (main.cu:195-345, tests/golden/k6_fa1_cases.npz: inputs and the outputs of the reference's naive check) with its
+    gate |d| < 1e-4, and l, m consistent with the oracle's log-sum-exp."""
+    import ctypes
+    import cuda_flashattention_amd as fa
+    import oracle
+    lib = fa._capi.lib()
+    g = golden("k6_fa1_cases.npz")
+    names = sorted({k[:-2] for k in g.keys() if k.endswith("_Q")})
+    assert len(names) >= 5
+    for nm in names:
+        Q, K, V, Oref = (np.ascontiguousarray(g[f"{nm}_{t}"], dtype=np.float32) for t in "QKVO")
+        N, d = Q.shape
+        dev = [torch.from_numpy(a).cuda() for a in (Q, K, V)]
+        O = torch.full((N, d), float("nan"), device="cuda")
+        l = torch.empty(N, device="cuda")
+        m = torch.empty(N, device="cuda")
+        st = lib.flash_attention(dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), O.data_ptr(), l.data_ptr(), m.data_ptr(),
+                                 N, d, 32, 1024)
+        assert st == 0
+        torch.cuda.synchronize()
+        assert np.abs(O.cpu().numpy() - Oref).max() < 1e-4, nm
+        _, Lr = oracle.naive_forward_pass(Q, K, V, float(1.0 / np.sqrt(d)))
+        assert np.abs((m + torch.log(l)).cpu().numpy() - Lr).max() < 1e-4, nm
+
+
+def test_fa1_baseline_matches_oracle_medium():
+    import cuda_flashattention_amd as fa
+    import oracle
+    lib = fa._capi.lib()
+    rng = np.random.default_rng(3)
+    for N, d in ((300, 64), (1000, 128), (77, 5)):
+        Q, K, V = (rng.uniform(-0.5, 0.5, (N, d)).astype(np.float32) for _ in range(3))
+        dev = [torch.from_numpy(a).cuda() for a in (Q, K, V)]
+        O = torch.empty(N, d, device="cuda")
+        l = torch.empty(N, device="cuda")
+        m = torch.empty(N, device="cuda")
+        assert lib.flash_attention(dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), O.data_ptr(), l.data_ptr(), m.data_ptr(),
+                                   N, d, 32, 1024) == 0
+        torch.cuda.synchronize()
+        Or, Lr = oracle.naive_forward_pass(Q, K, V, float(1.0 / np.sqrt(d)))
+        assert np.abs(O.cpu().numpy() - Or).max() < 1e-5
+        assert np.abs((m + torch.log(l)).cpu().numpy() - Lr).max() < 1e-4
+    one = ctypes_void = None
+    assert lib.flash_attention(None, None, None, None, None, None, 4, 4, 32, 1024) == -1

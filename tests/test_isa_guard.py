@@ -27,7 +27,7 @@ CSRC = os.path.join(ROOT, "cuda_flashattention_amd", "csrc")
 def asm():
     subprocess.check_call(["make", "-s", "-j", "4", "-C", CSRC, "asm"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     out = {}
-    for f in ("fa2_fwd_bf16", "fa2_bwd_bf16", "fa2_fwd_fp8", "fa2_f32", "fa2_util"):
+    for f in ("fa2_fwd_bf16", "fa2_bwd_bf16", "fa2_fwd_fp8", "fa2_f32", "fa2_util", "fa1_f32"):
         out[f] = open(os.path.join(CSRC, "_obj", f + ".s")).read()
     return out
 
@@ -79,14 +79,16 @@ def _main_loop(body):
     return body[lo:hi]
 
 
-PRODUCT = ("fa2_fwd_bf16", "fa2_bwd_bf16", "fa2_fwd_fp8", "fa2_f32", "fa2_util")
+PRODUCT = ("fa2_fwd_bf16", "fa2_bwd_bf16", "fa2_fwd_fp8", "fa2_f32", "fa2_util", "fa1_f32")
 
 
 def test_no_scratch_no_spill(asm):
     bad = []
     for f in PRODUCT:
         for name, k in _kernels(asm[f]).items():
-            if k["meta"]["scratch"] or k["meta"]["vgpr_spill"]:
+            # scratch memory: never.  VGPR "spills" into free AGPRs are tolerated only in the didactic FA1 kernel (no
+            # hand-named registers there; its two 128-float rows per lane simply do not fit 256 VGPRs).
+            if k["meta"]["scratch"] or (k["meta"]["vgpr_spill"] and f != "fa1_f32"):
                 bad.append((name, k["meta"]))
     assert not bad, bad
 
