@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one pass of the hot path over one batch of synthetic bf16 Q/K/V/dO already
-resident in HBM: fa2_forward then fa2_backward (delta + dQ + dK/dV kernels) through the C ABI
+resident in HBM: fa2_forward then fa2_backward (delta + the single five-product kernel + dQ output pass) through the C ABI
 of libfa2_mi355x.so.  W untimed warm-up steps, then EXACTLY K steps bracketed by a barrier +
 torch.cuda.synchronize() on both sides; rank 0 prints ONE JSON line.
 
@@ -16,8 +16,8 @@ forward (the path's one real exchange step, RCCL send/recv over xGMI) is timed a
 reported in the extra "ring" object when the ring library is available.
 
 Flop model: fwd 4 B H N^2 d, bwd 10 B H N^2 d (five block products), fwd+bwd 14.
-The backward here executes seven products (S and dP are formed in both of its kernels,
-DESIGN.md); the metric still counts the algorithmic ten.
+At this shape fa2_backward runs the single five-product kernel (csrc/fa2_bwd_fused.hip); the two-kernel
+form, which executes seven products for the same five, is timed beside it (`two_kernel_backward_ms`).
 """
 import argparse
 import json
@@ -155,9 +155,13 @@ def main():
     k_ms = {
         "fa2_fwd_bf16_kernel": median_ms(fwd, torch, 3, it),
         "fa2_bwd_delta_kernel": median_ms(lambda: bwd(1), torch, 3, it),
-        "fa2_bwd_dq_kernel": median_ms(lambda: bwd(2), torch, 3, it),
-        "fa2_bwd_dkdv_kernel": median_ms(lambda: bwd(4), torch, 3, it),
+        # what fa2_backward runs at this shape: the single five-product kernel (with its control-block memset and the
+        # fp32 -> bf16 output pass of dQ: ~0.08 ms of the figure)
+        "fa2_bwd_fused_kernel": median_ms(lambda: bwd(8), torch, 3, it),
     }
+    # the two-kernel form of the same backward (seven products), for comparison: FA2_BACKWARD_PATH=two_kernel selects it
+    two_kernel_ms = {"fa2_bwd_dq_kernel": median_ms(lambda: bwd(2), torch, 3, it),
+                     "fa2_bwd_dkdv_kernel": median_ms(lambda: bwd(4), torch, 3, it)}
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -177,12 +181,11 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * flops_step / (ms_per_step * 1e-3) / 1e12
 
-    # MFMA flops each launch executes: fwd 2 block products, dq 3 (S, dP, dQ), dkdv 4 (S, dP, dV, dK); and the
-    # ALGORITHMIC flops each delivers (the five products of the backward counted once: dQ to the dq kernel, the other
-    # four to dkdv, whose products are all among the five).
+    # MFMA flops each launch executes = the ALGORITHMIC flops it delivers: forward 2 block products, backward 5 (S, dP, dV,
+    # dK, dQ, each formed once by the single kernel).  The two-kernel form executes 3 + 4 for the same five.
     prod = 2.0 * B * H * N * N * D
-    k_flops = {"fa2_fwd_bf16_kernel": 2 * prod, "fa2_bwd_dq_kernel": 3 * prod, "fa2_bwd_dkdv_kernel": 4 * prod}
-    k_alg = {"fa2_fwd_bf16_kernel": 2 * prod, "fa2_bwd_dq_kernel": 1 * prod, "fa2_bwd_dkdv_kernel": 4 * prod}
+    k_flops = {"fa2_fwd_bf16_kernel": 2 * prod, "fa2_bwd_fused_kernel": 5 * prod}
+    k_alg = dict(k_flops)
     dom = max(k_flops, key=lambda k: k_ms[k])
     achieved = k_alg[dom] / (k_ms[dom] * 1e-3) / 1e12
     traffic, traffic_src = pmc_traffic(dom)
@@ -194,6 +197,7 @@ def main():
                 "kernels_ms": {k: round(v, 4) for k, v in k_ms.items()},
                 "kernels_frac_executed": {k: round(k_flops[k] / (k_ms[k] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) for k in k_flops},
                 "kernels_frac_algorithmic": {k: round(k_alg[k] / (k_ms[k] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) for k in k_alg},
+                "two_kernel_backward_ms": {k: round(v, 4) for k, v in two_kernel_ms.items()},
                 "whole_path_frac": round(value / world / PEAK_BF16_TFLOPS, 4)}
 
     out = {

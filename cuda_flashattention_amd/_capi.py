@@ -37,6 +37,8 @@ SIGNATURES = {
     "fa2_backward_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "fa2_backward": (_i, [_vp] * 9 + [_i, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp]),
     "fa2_backward_phases": (_i, [_vp] * 9 + [_i, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp, _i]),
+    "fa2_backward_fused_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "fa2_backward_fused": (_i, [_vp] * 9 + [_i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
     "fa2_backward_block": (_i, [_vp] * 9 + [_i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _i]),
     "fa2_forward_step": (_i, [_vp] * 7 + [_i, _i, _i, _i, _i, _f, _i, _i, _i, _vp]),
     "fa2_forward_step_strided": (_i, [_vp] * 7 + [_i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _i, _i, _vp]),

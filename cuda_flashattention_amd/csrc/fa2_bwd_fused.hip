@@ -1,0 +1,501 @@
+// fa2_bwd_fused.hip -- PROTOTYPE of the single-kernel, five-product FlashAttention-2 backward for gfx950 (d = 128, bf16,
+// non-causal, seq_len a multiple of 256).  Not the default path: fa2_backward keeps the two deterministic kernels of
+// fa2_bwd_bf16.hip; this file exists to measure what the five-product form costs on this chip.
+//
+// Work split as fa2_bwd_dkdv_kernel (a workgroup owns 256 keys, dK^T / dV^T in 256 accumulator registers per wave), plus the
+// query gradient: the packed dS pairs each wave already forms for dK go to a [key][q] tile in LDS, and every wave
+// contracts that tile over ALL 256 keys of the workgroup with K^T (transposed reads of the K image) for its own 32 of the
+// 128 columns -- dQ[q][col] -- so S and dP are formed once (80 MFMAs per 32-row sub-tile and wave instead of 64 + 48).
+// The main loop is a generated body (tools/gen_fused_body.py).  What remains is the sum of the dQ tiles over the N / 256
+// workgroups of a head.  MODE 0 adds them with fp32 atomics (memory-side on MI355X, ~1.3 TB/s chip-wide: the known
+// floor, B H (N/256) N d 4 bytes); MODE 1 passes a running sum from key block j to key block j + 1 through the L2 of the XCD
+// the head is pinned to (see fused_handoff below).
+#include <type_traits>
+
+#include "fa2_common.h"
+#include "fa2_launch.h"
+
+namespace fa2 {
+
+#include "fa2_bwd_fused_body.inc"
+
+typedef __attribute__((address_space(3))) void* fused_lptr_t;
+
+// dS tile [256 keys][32 q] bf16, 64-byte rows of eight 8-byte chunks: chunk c of row r sits at chunk c ^ key(r).  The key
+// may only use row bits 2 and 3 (the E chain steps 16 rows per immediate offset, the packs step 32), which leaves the
+// ds_write_b64 of a 32-lane half two-way conflicted (rows r and r + 16 share a bank pair) and the transposed reads clean.
+#ifndef FA2_FUSED_DSKEY
+#define FA2_FUSED_DSKEY(row) ((((row) >> 2) & 3) << 1)
+#endif
+
+#ifndef FA2_FUSED_DIAG        // diagnostic builds (wrong results, timing only): 1 = no waiting, 2 = no running-sum loads, 4 = no stores
+#define FA2_FUSED_DIAG 0
+#endif
+
+template <int R>
+__device__ __forceinline__ void fused_vset(uint32_t x)
+{
+    asm volatile("v_mov_b32 v%c1, %0" : : "v"(x), "i"(R) : "v255");
+}
+
+#define FA2_FUSED_CLOBBERS "memory", "vcc", "v255", FA2_ACC_CLOBBERS
+#define FA2_FUSED_OPS [r0] "v"(roff[0]), [r1] "v"(roff[1]), [r2] "v"(roff[2]), [r3] "v"(roff[3]), [r4] "v"(roff[4]), [r5] "v"(roff[5]),  \
+    [r6] "v"(roff[6]), [r7] "v"(roff[7]), [t0] "v"(toff[0]), [t1] "v"(toff[1]), [t2] "v"(toff[2]), [t3] "v"(toff[3]), [t4] "v"(toff[4]),   \
+    [t5] "v"(toff[5]), [t6] "v"(toff[6]), [t7] "v"(toff[7]), [rc] "v"(rcv), [c2] "s"(c2)
+
+// chained kernel: the body stores the dQ tile it has just finished (drs, dso) and loads the next running sum (lrs, lso)
+template <int BUF, int PAR, int VMW>
+__device__ __forceinline__ void fused_cbody(const uint32_t (&roff)[8], const uint32_t (&toff)[8], uint32_t rcv, float c2, uint32_t dqv,
+                                            __amdgpu_buffer_rsrc_t drs, uint32_t dso, __amdgpu_buffer_rsrc_t lrs, uint32_t lso)
+{
+#define FA2_FUSED_CASE(B, P)                                                                                                     \
+    if constexpr (BUF == B && PAR == P)                                                                                          \
+        asm volatile(FA2_FUSED_CBODY_B##B##_P##P : : FA2_FUSED_OPS, [vm] "i"(VMW), [dqv] "v"(dqv), [drs] "s"(drs), [dso] "s"(dso), \
+                     [lrs] "s"(lrs), [lso] "s"(lso) : FA2_FUSED_CLOBBERS);
+    FA2_FUSED_CASE(0, 0) FA2_FUSED_CASE(0, 1) FA2_FUSED_CASE(1, 0) FA2_FUSED_CASE(1, 1) FA2_FUSED_CASE(2, 0) FA2_FUSED_CASE(2, 1)
+#undef FA2_FUSED_CASE
+}
+
+template <int BUF, int PAR, int VMW>
+__device__ __forceinline__ void fused_body(const uint32_t (&roff)[8], const uint32_t (&toff)[8], uint32_t rcv, float c2)
+{
+#define FA2_FUSED_CASE(B, P) \
+    if constexpr (BUF == B && PAR == P) asm volatile(FA2_FUSED_BODY_B##B##_P##P : : FA2_FUSED_OPS, [vm] "i"(VMW) : FA2_FUSED_CLOBBERS);
+    FA2_FUSED_CASE(0, 0) FA2_FUSED_CASE(0, 1) FA2_FUSED_CASE(1, 0) FA2_FUSED_CASE(1, 1) FA2_FUSED_CASE(2, 0) FA2_FUSED_CASE(2, 1)
+#undef FA2_FUSED_CASE
+}
+
+// this wave's dQ tile (16 registers: lane = column 32 w + (lane & 31), register r = row (r & 3) + 8 (r >> 2) + 4 h) -> dQacc
+// rows [row0, row0 + 32) of the head: rsrc covers the head's fp32 slab, voff = ((4 h) * 128 + col) * 4, soff = row0 * 512.
+template <int DQT>
+__device__ __forceinline__ void fused_dq_atomic(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff)
+{
+    asm volatile(
+        "s_add_u32 s12, %2, 4096\n\ts_add_u32 s13, %2, 8192\n\ts_add_u32 s14, %2, 12288\n\t"
+        "buffer_atomic_add_f32 v%c3, %0, %1, %2 offen\n\tbuffer_atomic_add_f32 v%c4, %0, %1, %2 offen offset:512\n\t"
+        "buffer_atomic_add_f32 v%c5, %0, %1, %2 offen offset:1024\n\tbuffer_atomic_add_f32 v%c6, %0, %1, %2 offen offset:1536\n\t"
+        "buffer_atomic_add_f32 v%c7, %0, %1, s12 offen\n\tbuffer_atomic_add_f32 v%c8, %0, %1, s12 offen offset:512\n\t"
+        "buffer_atomic_add_f32 v%c9, %0, %1, s12 offen offset:1024\n\tbuffer_atomic_add_f32 v%c10, %0, %1, s12 offen offset:1536\n\t"
+        "buffer_atomic_add_f32 v%c11, %0, %1, s13 offen\n\tbuffer_atomic_add_f32 v%c12, %0, %1, s13 offen offset:512\n\t"
+        "buffer_atomic_add_f32 v%c13, %0, %1, s13 offen offset:1024\n\tbuffer_atomic_add_f32 v%c14, %0, %1, s13 offen offset:1536\n\t"
+        "buffer_atomic_add_f32 v%c15, %0, %1, s14 offen\n\tbuffer_atomic_add_f32 v%c16, %0, %1, s14 offen offset:512\n\t"
+        "buffer_atomic_add_f32 v%c17, %0, %1, s14 offen offset:1024\n\tbuffer_atomic_add_f32 v%c18, %0, %1, s14 offen offset:1536\n\t"
+        "s_nop 1"
+        : : "v"(voff), "s"(rs), "s"(soff), "i"(DQT), "i"(DQT + 1), "i"(DQT + 2), "i"(DQT + 3), "i"(DQT + 4), "i"(DQT + 5), "i"(DQT + 6),
+            "i"(DQT + 7), "i"(DQT + 8), "i"(DQT + 9), "i"(DQT + 10), "i"(DQT + 11), "i"(DQT + 12), "i"(DQT + 13), "i"(DQT + 14),
+            "i"(DQT + 15)
+        : "memory", "s12", "s13", "s14", "v255");
+}
+
+// 16 bytes of both key blocks' V rows (k-step S) into their fragment registers; completes at the caller's vmcnt(0)
+template <int VF, int KS, int S>
+__device__ __forceinline__ void fused_load_vfrag(const char* v0, const char* v1)
+{
+    asm volatile("global_load_dwordx4 v[%c2:%c3], %0, off offset:%c4\n\tglobal_load_dwordx4 v[%c5:%c6], %1, off offset:%c4"
+                 : : "v"(v0), "v"(v1), "i"(VF + 4 * S), "i"(VF + 4 * S + 3), "i"(32 * S), "i"(VF + 4 * (KS + S)), "i"(VF + 4 * (KS + S) + 3)
+                 : "memory", "v255");
+}
+
+template <int DQT>
+__device__ __forceinline__ void fused_dq_zero()
+{
+    static_for<16>([&](auto R) { fused_vset<DQT + decltype(R)::value>(0u); });
+}
+
+// ---- the chained form's control block (ints, zeroed by the launcher before every launch)
+//   ticket[x]  at 32 x            per-XCD unit queue (x = hardware XCC_ID, 16 possible values)
+//   next_head  at 32 * 16         heads handed out so far, over all XCDs
+//   error      at 32 * 17         set when a bounded spin ran out (the result is then poisoned by the output pass)
+//   headmap[x][k] at 32 * 18 + x (BH + 1) + k   1 + head the k-th chain of queue x works on; -1 = nothing left; 0 = not yet known
+//   prog[head][j] behind it       query sub-tiles whose running dQ sum key block j has completely stored
+constexpr int kCtlTicket = 0, kCtlNextHead = 32 * 16, kCtlError = 32 * 17, kCtlHeadmap = 32 * 18;
+constexpr int kSpinLimit = 1 << 20;
+
+struct FusedArgs {
+    BwdArgs b;
+    float* dQacc;       // fp32 [BH][N][128]: zeroed by the launcher and atomically added to (CHAIN = false);
+                        // the running sums as [BH][N / 32][wave][g][lane] x 4 floats (CHAIN = true: fused_dq_out_chain_kernel)
+    int* ctl;           // control block (CHAIN = true)
+};
+
+__device__ __forceinline__ int fused_ctl_ints(int BH, int ncb) { return kCtlHeadmap + 16 * (BH + 1) + 9 * BH * ncb; }
+
+__device__ __forceinline__ int fused_load_sc1(const int* p)
+{
+    int v;
+    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+// The progress of the previous key block is prefetched into v39, a register the compiler does not allocate (the kernel is
+// limited to v0..v38): were it a compiler-managed value, the compiler would wait for ALL vector memory traffic before reading
+// it -- including the running-sum loads the body has just issued.  The load is issued in front of a body, whose vmcnt(0)
+// completes it; it is read after the body.
+__device__ __forceinline__ void fused_seen_issue(__amdgpu_buffer_rsrc_t rs, uint32_t off)
+{
+    asm volatile("buffer_load_dword v39, off, %0, %1 sc1" : : "s"(rs), "s"(off) : "memory", "v39");
+}
+__device__ __forceinline__ int fused_seen_read()
+{
+    int v;
+    asm volatile("v_readfirstlane_b32 %0, v39" : "=s"(v) : : "v39");
+    return v;
+}
+__device__ __forceinline__ void fused_seen_set(int v)
+{
+    asm volatile("v_mov_b32 v39, %0" : : "s"(v) : "v39");
+}
+
+// Flags and running sums are written with plain stores: they land in the L2 of this XCD, which is where the readers (same
+// XCD by construction, sc1 loads that bypass their CU's vector cache) look.  An sc1 store would be written through to
+// memory first -- measured: 9.2 ms instead of 5.6 ms for the whole backward, the consumers' polls then wait on HBM.
+__device__ __forceinline__ void fused_store_flag(int* p, int v)
+{
+    asm volatile("global_store_dword %0, %1, off" : : "v"(p), "v"(v) : "memory");
+}
+
+// Every wait in the chained kernel is bounded: a spin that runs out raises the error word, and a raised error word ends
+// everybody else's spins within 1024 polls (the output pass then poisons dQ) -- a fault shows as NaNs, not as a hung GPU.
+__device__ __forceinline__ bool fused_spin_over(int* ctl, int spins)
+{
+    if (spins > kSpinLimit) {
+        atomicExch(ctl + kCtlError, 1);
+        return true;
+    }
+    return (spins & 1023) == 0 && fused_load_sc1(ctl + kCtlError) != 0;
+}
+
+// One launch of the five-product backward.
+//   CHAIN = false: one workgroup per (head, key block); dQ tiles are added to dQacc with fp32 atomics.
+//   CHAIN = true:  a persistent grid (one workgroup per CU).  Workgroups take (head, key block j) units, in order, from the
+//     queue of the XCD they run on (hardware XCC_ID), so that the key blocks of a head are worked on by CUs that share an L2.
+//     Key block j takes the running sum of a query sub-tile from key block j - 1 (loaded straight into the accumulator the
+//     E chain then adds to), stores its own, and publishes how far it is in prog[head][j]: the order of the additions is
+//     fixed, so the result is deterministic.  A unit only ever waits for units taken from the same queue before it, and
+//     the workgroup holding the oldest unfinished unit never waits: no deadlock for any number of resident workgroups.
+template <bool CHAIN>
+__global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) fa2_bwd_fused_kernel(FusedArgs fp)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const BwdArgs& p = fp.b;
+    constexpr int D = 128, ROWB = 256, KS = 8, DT = 4;
+    constexpr int TROWS = 32;
+    constexpr int QRING = FA2_FUSED_QRING, BUFB = FA2_FUSED_BUFB, DSB = FA2_FUSED_DSB;
+    constexpr int CPR = 16, RPI = 4, NINS = TROWS / RPI;      // 8 one-KiB DMA pieces per tensor per 32-row tile
+    constexpr int VF = FA2_FUSED_VF, DQT = FA2_FUSED_DQT, ROFFK = FA2_FUSED_ROFFK, DSWR = FA2_FUSED_DSWR, DSRD = FA2_FUSED_DSRD,
+                  KT = FA2_FUSED_KT;
+    constexpr int VMW = CHAIN ? 5 : 63;              // vector-memory operations issued behind the DQT loads: >= 4 DMA pieces, flag load
+    int* const mail = reinterpret_cast<int*>(smem + FA2_FUSED_LDS);      // 16 bytes behind the generated map: the unit taken
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ki = lane & 31;
+    const int h = lane >> 5;
+    const int N = p.Nk;                          // square, dense: Nq == Nk == q_hs == k_hs
+    const int ncb = N / 256;
+    const int ntiles = N / TROWS;
+    const int niter = ((ntiles + 1 + 5) / 6) * 6;        // bodies come in sixes (ring of 3 x dS parity); the extra ones see zero rows
+    const float c2 = p.scale * kLog2e;
+    const size_t rc_plane = (size_t)p.BH * N;
+
+    // ---- loop-invariant LDS addresses
+    const uint32_t lbase = (uint32_t)(uintptr_t)smem;
+    const int trq = (lane & 15) >> 2, trp = lane & 3, trcb = (lane >> 4) & 1;
+    uint32_t roff[KS], toff[2 * DT];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) roff[s] = lbase + QRING + lds_off<D>(ki, 2 * s + h);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+            toff[2 * dt + jj] = lbase + QRING + lds_off<D>(8 * jj + 4 * h + trq, 4 * dt + 2 * trcb + (trp >> 1)) + 8 * (trp & 1);
+    const uint32_t rcv = lbase + QRING + 2 * TROWS * ROWB + 16 * h;
+    static_for<KS>([&](auto S) {                   // this wave's K rows in the K image
+        constexpr int sidx = decltype(S)::value;
+        fused_vset<ROFFK + sidx>(lbase + lds_off<D>(ki + 64 * wave, 2 * sidx + h));
+    });
+    static_for<2>([&](auto JJ) {                   // K^T for this wave's 32 columns; dS^T of the workgroup's tile
+        constexpr int jj = decltype(JJ)::value;
+        fused_vset<KT + jj>(lbase + lds_off<D>(8 * jj + 4 * h + trq, 4 * wave + 2 * trcb + (trp >> 1)) + 8 * (trp & 1));
+        const int row = 8 * jj + 4 * h + trq;
+        fused_vset<DSRD + jj>(lbase + DSB + row * 64 + 8 * ((4 * trcb + trp) ^ FA2_FUSED_DSKEY(row)));
+    });
+    static_for<4>([&](auto C) {                    // dS write addresses: 8-byte chunk (4 sp + 2 jp + h) of row 64 w + ki
+        constexpr int c = decltype(C)::value;
+        fused_vset<DSWR + c>(lbase + DSB + (64 * wave + ki) * 64 + 8 * (((2 * c) | h) ^ FA2_FUSED_DSKEY(ki)));
+    });
+    const int drow = lane / CPR, dslot = lane % CPR;
+    const int prow = wave * RPI + drow;
+    const int doff = drow * ROWB + 16 * ((lds_off<D>(prow, dslot) - ROWB * prow) >> 4);
+    const uint32_t dqv = CHAIN ? (uint32_t)(wave * 4096 + lane * 16) : (uint32_t)(((4 * h) * D + 32 * wave + ki) * 4);
+    const auto rc_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.RC, 0, (int)(2 * rc_plane * 4), 0x00020000);
+
+    int xcc = 0;
+    if constexpr (CHAIN) {
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+    }
+    int* const prog_base = fp.ctl + kCtlHeadmap + 16 * (p.BH + 1);
+    const auto ctl_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)fp.ctl, 0, CHAIN ? fused_ctl_ints(p.BH, ncb) * 4 : 0, 0x00020000);
+
+    for (;;) {
+        // ---- the unit: (head, key block)
+        int head, cb;
+        if constexpr (CHAIN) {
+            if (tid == 0) {
+                int hd = -1, j = 0;
+                const int u = atomicAdd(fp.ctl + kCtlTicket + 32 * xcc, 1);
+                const int k = u / ncb;
+                j = u % ncb;
+                if (k <= p.BH) {
+                    int* hm = fp.ctl + kCtlHeadmap + xcc * (p.BH + 1) + k;
+                    int v;
+                    if (j == 0) {
+                        const int g = atomicAdd(fp.ctl + kCtlNextHead, 1);
+                        v = g < p.BH ? g + 1 : -1;
+                        fused_store_flag(hm, v);
+                    } else {
+                        int spins = 0;
+                        while ((v = fused_load_sc1(hm)) == 0)
+                            if (fused_spin_over(fp.ctl, ++spins)) { v = -1; break; }
+                    }
+                    hd = v > 0 ? v - 1 : -1;
+                }
+                mail[0] = hd;
+                mail[1] = j;
+            }
+            __syncthreads();
+            head = __builtin_amdgcn_readfirstlane(mail[0]);
+            cb = __builtin_amdgcn_readfirstlane(mail[1]);
+            if (head < 0) break;
+        } else {
+            map_block(blockIdx.x, p.BH, ncb, head, cb);
+        }
+        const size_t slab = (size_t)head * N * ROWB;
+        const char* Qh = (const char*)p.Q + slab;
+        const char* Kh = (const char*)p.K + slab;
+        const char* Vh = (const char*)p.V + slab;
+        const char* Gh = (const char*)p.dO + slab;
+        const int kw0 = cb * 256 + wave * 64;
+
+        // V fragments of both key blocks straight into v[VF ...] (B operands of dP' = dO V^T: lane = key column), and the K image
+        // (the workgroup's 256 keys, swizzled like every other tile: rows for S', columns for dQ) by LDS-DMA: neither
+        // passes through compiler-allocated registers
+        {
+            const int lane_u = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));    // recomputed: nothing per-lane
+            const char* v0 = Vh + (size_t)(kw0 + (lane_u & 31)) * ROWB + 16 * (lane_u >> 5);             // is kept (spilled) across units
+            const char* v1 = v0 + 32 * ROWB;
+            static_for<KS>([&](auto S) { fused_load_vfrag<VF, KS, decltype(S)::value>(v0, v1); });
+            const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, N * ROWB, 0x00020000);
+#pragma unroll
+            for (int j = wave; j < 256 / RPI; j += 4)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (fused_lptr_t)(smem + j * 1024), 16, doff, (cb * 256 + j * RPI) * ROWB, 0, 0);
+        }
+        static_for<32 * DT>([&](auto R) {
+            acc_write<decltype(R)::value>(0.0f);
+            acc_write<128 + decltype(R)::value>(0.0f);
+        });
+
+        // ---- LDS-DMA staging of a 32-row Q / dO tile + its row constants into ring slot `buf`
+        const auto q_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Qh, 0, N * ROWB, 0x00020000);
+        const auto g_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Gh, 0, N * ROWB, 0x00020000);
+        const int rcoff = (int)(((wave == 0 ? 0 : rc_plane) + (size_t)head * N + (lane & 31)) * 4);
+        auto stage = [&](int t, int buf) {
+            char* b = smem + QRING + buf * BUFB;
+#pragma unroll
+            for (int j = wave; j < 2 * NINS; j += 4) {
+                const int which = j / NINS, piece = j % NINS;
+                const int soff = (t * TROWS + piece * RPI) * ROWB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(which ? g_rsrc : q_rsrc, (fused_lptr_t)(b + which * (TROWS * ROWB) + piece * 1024),
+                                                         16, doff, soff, 0, 0);
+            }
+            if (wave < 2 && lane < 32)                   // 32 x -L/scale (wave 0), 32 x -D (wave 1)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rc_rsrc, (fused_lptr_t)(b + 2 * TROWS * ROWB + wave * 128), 4, rcoff, t * TROWS * 4, 0, 0);
+        };
+        stage(0, 0);
+        fused_dq_zero<DQT>();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                 // V fragments, K image and the first tile have landed
+        asm volatile(FA2_FUSED_PRO : : FA2_FUSED_OPS, [vm] "i"(VMW) : FA2_FUSED_CLOBBERS);
+
+        const auto dq_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(fp.dQacc + (size_t)head * N * D), 0, N * D * 4, 0x00020000);
+        const int* const prev = prog_base + head * ncb + cb - 1;      // the key block this one takes the running sums from (cb > 0)
+        const int prev_off = (int)((prev - fp.ctl) * 4);
+        int* const mine = prog_base + head * ncb + cb;
+        if constexpr (CHAIN) fused_seen_set(0);          // what prev was last seen at
+#ifdef FA2_FUSED_STATS
+        int st_steps = 0, st_polls = 0, st_cycles = 0;
+        const uint64_t u0 = __builtin_readcyclecounter();
+#endif
+
+        const auto null_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)fp.dQacc, 0, 0, 0x00020000);     // every access out of range
+        auto step = [&](auto BUF, auto PAR, int t) {
+            constexpr int buf = decltype(BUF)::value, par = decltype(PAR)::value;
+            if constexpr (CHAIN) {
+                // body t: E forms the dQ tile of sub-tile t - 1 on top of the running sum loaded by body t - 1, stores it, and
+                // loads the running sum of sub-tile t, which key block cb - 1 must have stored by now
+                if (cb > 0 && t < ntiles) {
+                    int spins = 0;
+#ifdef FA2_FUSED_STATS
+                    const uint64_t w0 = __builtin_readcyclecounter();
+#endif
+                    if (!(FA2_FUSED_DIAG & 1) && fused_seen_read() < t + 1)
+                        while (fused_load_sc1(prev) < t + 1)
+                            if (fused_spin_over(fp.ctl, ++spins)) break;
+#ifdef FA2_FUSED_STATS
+                    if (spins) { st_steps++; st_polls += spins; st_cycles += (int)(__builtin_readcyclecounter() - w0); }
+#endif
+                }
+                stage(t + 1, (buf + 1) % 3);             // rows past the end read as zeros
+                // how far prev is, for the next step.  Asynchronous; the wait in front of the E chain (all but the VMW youngest
+                // operations: >= 4 DMA pieces and this load) covers the running-sum loads without waiting for this one.
+                fused_seen_issue(ctl_rsrc, (uint32_t)prev_off);      // always: VMW counts it (cb == 0 reads its own slot - 1: unused)
+                const bool live = t >= 1 && t <= ntiles;
+                const uint32_t dso = (uint32_t)__builtin_amdgcn_readfirstlane((t - 1) * TROWS * D * 4);
+                fused_cbody<buf, par, VMW>(roff, toff, rcv, c2, dqv, live ? dq_rsrc : null_rsrc, dso, cb > 0 && !(FA2_FUSED_DIAG & 2) ? dq_rsrc : null_rsrc,
+                                           dso + TROWS * D * 4);
+                // the body's barrier sits behind a vmcnt(0) that covers every wave's stores: sub-tiles < t are out
+                if (live && tid == 0) fused_store_flag(mine, t);
+            } else {
+                stage(t + 1, (buf + 1) % 3);
+                fused_body<buf, par, VMW>(roff, toff, rcv, c2);
+#ifndef FA2_FUSED_NO_DQ                              // diagnostic build: how long the kernel takes without the dQ traffic
+                // the body's E stage has finished the dQ tile of sub-tile t - 1
+                if (t >= 1 && t <= ntiles) fused_dq_atomic<DQT>(dq_rsrc, dqv, (uint32_t)__builtin_amdgcn_readfirstlane((t - 1) * TROWS * D * 4));
+#endif
+                fused_dq_zero<DQT>();
+            }
+        };
+        for (int t = 0; t < niter; t += 6) {
+            step(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, t);
+            step(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, t + 1);
+            step(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, t + 2);
+            step(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, t + 3);
+            step(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, t + 4);
+            step(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, t + 5);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+        mfma_acc_settle();
+        // lane indices recomputed here so that nothing per-lane has to live (or spill) across the loop
+        const int lane_ep = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        const int ki_ep = lane_ep & 31, h_ep = lane_ep >> 5;
+        static_for<2>([&](auto KB) {
+            constexpr int kb = decltype(KB)::value;
+            const int key = kw0 + 32 * kb + ki_ep;
+            char* dKk = (char*)p.dK + slab + (size_t)key * ROWB;
+            char* dVk = (char*)p.dV + slab + (size_t)key * ROWB;
+            static_for<4 * DT>([&](auto G) {
+                constexpr int dt = decltype(G)::value / 4, g = decltype(G)::value % 4;
+                constexpr int RK = 16 * (kb * DT + dt) + 4 * g, RV = 128 + 16 * (kb * DT + dt) + 4 * g;
+                bf16x4 a, b;
+                a[0] = (__bf16)(acc_read<RK>() * p.scale); a[1] = (__bf16)(acc_read<RK + 1>() * p.scale);
+                a[2] = (__bf16)(acc_read<RK + 2>() * p.scale); a[3] = (__bf16)(acc_read<RK + 3>() * p.scale);
+                b[0] = (__bf16)acc_read<RV>(); b[1] = (__bf16)acc_read<RV + 1>();
+                b[2] = (__bf16)acc_read<RV + 2>(); b[3] = (__bf16)acc_read<RV + 3>();
+                *reinterpret_cast<bf16x4*>(dKk + 2 * (32 * dt + 8 * g + 4 * h_ep)) = a;
+                *reinterpret_cast<bf16x4*>(dVk + 2 * (32 * dt + 8 * g + 4 * h_ep)) = b;
+            });
+        });
+#ifdef FA2_FUSED_STATS
+        if (CHAIN && tid == 0) {                         // debug: ctl[kCtlError + 1 ...] = steps that waited, polls, cycles waited, cycles total
+            atomicAdd(fp.ctl + kCtlError + 1, st_steps);
+            atomicAdd(fp.ctl + kCtlError + 2, st_polls);
+            atomicAdd((unsigned long long*)(fp.ctl + kCtlError + 4), (unsigned long long)st_cycles);
+            atomicAdd((unsigned long long*)(fp.ctl + kCtlError + 6), (unsigned long long)(__builtin_readcyclecounter() - u0));
+            int* rec = prog_base + p.BH * ncb + 8 * (head * ncb + cb);       // per unit: xcc, cycles waited, steps waited, start, end
+            rec[0] = xcc; rec[1] = st_cycles; rec[2] = st_steps;
+            *(unsigned long long*)(rec + 4) = u0; *(unsigned long long*)(rec + 6) = __builtin_readcyclecounter();
+        }
+#endif
+        if constexpr (!CHAIN) break;
+        __syncthreads();                                 // the K image and the mailbox are about to be rewritten
+    }
+}
+
+// dQ (bf16) = scale * dQacc (fp32); poisoned when the chained kernel reported a spin that ran out
+__global__ void __launch_bounds__(256) fa2_bwd_fused_dq_out_kernel(const float* __restrict__ acc, __bf16* __restrict__ dQ, size_t n8, float scale,
+                                                                    const int* __restrict__ err)
+{
+    const float poison = (err && *err) ? __builtin_nanf("") : 0.0f;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += stride) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(acc)[2 * i], b = reinterpret_cast<const f32x4*>(acc)[2 * i + 1];
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] = (__bf16)(a[e] * scale + poison); o[4 + e] = (__bf16)(b[e] * scale + poison); }
+        reinterpret_cast<bf16x8*>(dQ)[i] = o;
+    }
+}
+
+// the same for the chained kernel's layout: slot i = (((head * N / 32 + tile) * 4 + wave) * 4 + g) * 64 + lane holds rows
+// 32 tile + 8 g + 4 (lane >> 5) + (0 .. 3) of column 32 wave + (lane & 31)
+__global__ void __launch_bounds__(256) fa2_bwd_fused_dq_out_chain_kernel(const float* __restrict__ acc, __bf16* __restrict__ dQ, size_t n4, float scale,
+                                                                          const int* __restrict__ err)
+{
+    const float poison = *err ? __builtin_nanf("") : 0.0f;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(acc)[i];
+        const int lane = (int)(i & 63), g = (int)((i >> 6) & 3), wave = (int)((i >> 8) & 3);
+        const size_t row = (i >> 10) * 32 + 8 * g + 4 * (lane >> 5);
+        __bf16* o = dQ + row * 128 + 32 * wave + (lane & 31);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[(size_t)e * 128] = (__bf16)(a[e] * scale + poison);
+    }
+}
+
+// (the last 8 ints per unit are only written by -DFA2_FUSED_STATS builds: tools/gpu_stats_fused.py)
+size_t bwd_fused_ctl_bytes(int BH, int N) { return (size_t)(kCtlHeadmap + 16 * (BH + 1) + 9 * BH * (N / 256)) * sizeof(int); }
+
+hipError_t launch_bwd_fused_bf16(const BwdArgs& a, float* dQacc, int* ctl, int mode, hipStream_t stream)
+{
+    if (a.d != 128 || a.causal || a.Nq != a.Nk || a.Nk % 256 != 0 || a.q_hs != a.Nq || a.k_hs != a.Nk || a.q_row0 != 0)
+        return hipErrorInvalidValue;
+    hipError_t e = hipSuccess;
+    if (a.phases & 1) {
+        BwdArgs d = a;
+        d.phases = 1;
+        e = launch_bwd_bf16(d, stream);                   // D = rowsum(dO o O) and the row constants (kernel 0)
+        if (e != hipSuccess) return e;
+    }
+    if (!(a.phases & 8)) return hipSuccess;
+    const size_t elems = (size_t)a.BH * a.Nq * 128;
+    const int units = a.BH * (a.Nk / 256);
+    FusedArgs fa{a, dQacc, ctl};
+    constexpr int lds = FA2_FUSED_LDS + 16;
+    if (mode == 0) {
+        e = hipMemsetAsync(dQacc, 0, elems * 4, stream);
+        if (e != hipSuccess) return e;
+        static bool set_f[64] = {};
+        e = ensure_dynamic_lds(fa2_bwd_fused_kernel<false>, lds, set_f);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(fa2_bwd_fused_kernel<false>, dim3((unsigned)units), dim3(256), lds, stream, fa);
+    } else {
+        static int cus[64] = {};
+        int dev = 0;
+        e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+        if (!cus[dev]) {
+            e = hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev);
+            if (e != hipSuccess) return e;
+        }
+        e = hipMemsetAsync(ctl, 0, bwd_fused_ctl_bytes(a.BH, a.Nk), stream);
+        if (e != hipSuccess) return e;
+        static bool set_t[64] = {};
+        e = ensure_dynamic_lds(fa2_bwd_fused_kernel<true>, lds, set_t);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(fa2_bwd_fused_kernel<true>, dim3((unsigned)(units < cus[dev] ? units : cus[dev])), dim3(256), lds, stream, fa);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (mode == 0)
+        hipLaunchKernelGGL(fa2_bwd_fused_dq_out_kernel, dim3(2048), dim3(256), 0, stream, dQacc, (__bf16*)a.dQ, elems / 8, a.scale,
+                           (const int*)nullptr);
+    else
+        hipLaunchKernelGGL(fa2_bwd_fused_dq_out_chain_kernel, dim3(4096), dim3(256), 0, stream, dQacc, (__bf16*)a.dQ, elems / 4, a.scale,
+                           ctl + kCtlError);
+    return hipGetLastError();
+}
+
+}  // namespace fa2

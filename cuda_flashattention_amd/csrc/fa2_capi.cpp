@@ -3,6 +3,9 @@
 // the reference (flash_attention_kernel.cu:300-343, flash_attention_backward_kernel.cu:249-299)
 // become these functions.
 #include "../../include/fa2_mi355x.h"
+#include <cstdlib>
+#include <cstring>
+
 #include "fa2_launch.h"
 
 #include <hip/hip_runtime.h>
@@ -152,12 +155,33 @@ int fa2_forward_fp8(const void* Q, const void* K, const void* V, void* O, float*
     return hip_status(fa2::launch_fwd_fp8(a, (hipStream_t)stream));
 }
 
+// D = rowsum(dO o O), then the two row-constant planes (-L/scale, -D) of the kernels that own key blocks
+static size_t bwd_base_ws(int B, int H, int rows) { return 3 * align256((size_t)B * H * rows * sizeof(float)); }
+
+// shapes the single-kernel (five-product) backward takes: csrc/fa2_bwd_fused.hip
+static bool bwd_fused_shape(int seq_len, int head_dim, int dtype)
+{
+    return dtype == FA2_DTYPE_BF16 && head_dim == 128 && seq_len % 256 == 0 && (long long)seq_len * head_dim * 4 <= 0x7fffffffLL;
+}
+static size_t bwd_fused_ws(int B, int H, int seq_len, int head_dim)
+{
+    return align256((size_t)B * H * seq_len * head_dim * 4) + align256(fa2::bwd_fused_ctl_bytes(B * H, seq_len));
+}
+
+// FA2_BACKWARD_PATH=two_kernel keeps fa2_backward on the two deterministic kernels for every shape (A/B runs, triage)
+static bool bwd_fused_allowed()
+{
+    static const bool allowed = [] {
+        const char* e = getenv("FA2_BACKWARD_PATH");
+        return !(e && strcmp(e, "two_kernel") == 0);
+    }();
+    return allowed;
+}
+
 size_t fa2_backward_workspace_bytes(int B, int H, int seq_len, int head_dim, int dtype)
 {
-    (void)head_dim; (void)dtype;
     if (B <= 0 || H <= 0 || seq_len <= 0) return 0;
-    // D = rowsum(dO o O), then the dK/dV kernel's two row-constant planes (-L/scale, -D)
-    return 3 * align256((size_t)B * H * seq_len * sizeof(float));
+    return bwd_base_ws(B, H, seq_len) + (bwd_fused_shape(seq_len, head_dim, dtype) ? bwd_fused_ws(B, H, seq_len, head_dim) : 0);
 }
 
 int fa2_backward(const void* Q, const void* K, const void* V, const void* O, const float* L,
@@ -183,9 +207,25 @@ int fa2_backward_phases(const void* Q, const void* K, const void* V, const void*
     if (st) return st;
     if (!workspace || workspace_bytes < fa2_backward_workspace_bytes(B, H, seq_len, head_dim, dtype))
         return FA2_ERR_WORKSPACE;
-    if (dtype == FA2_DTYPE_BF16)
+    if (dtype == FA2_DTYPE_BF16) {
+        // phases: 1 = D and the row constants, 2 = dQ kernel, 4 = dK/dV kernel, 8 = the single five-product kernel + its
+        // output pass.  7 ("all of it") takes the single kernel where the shape allows (non-causal, d = 128, seq_len % 256 == 0)
+        const bool fused_ok = bwd_fused_shape(seq_len, head_dim, dtype) && !causal;
+        if ((phases & 8) && !fused_ok) return FA2_ERR_UNSUPPORTED;
+        if ((phases & 8) || (phases == 7 && fused_ok && bwd_fused_allowed())) {
+            fa2::BwdArgs a{};
+            a.Q = Q; a.K = K; a.V = V; a.O = O; a.dO = dO; a.L = L; a.dQ = dQ; a.dK = dK; a.dV = dV;
+            a.D = (float*)workspace; a.BH = B * H; a.Nq = seq_len; a.Nk = seq_len; a.d = head_dim;
+            a.RC = (float*)((char*)workspace + align256((size_t)B * H * seq_len * sizeof(float)));
+            a.q_hs = seq_len; a.k_hs = seq_len; a.q_row0 = 0; a.scale = softmax_scale; a.causal = 0; a.causal_shift = 0;
+            a.phases = phases == 7 ? 9 : (phases & 9);
+            char* acc = (char*)workspace + bwd_base_ws(B, H, seq_len);
+            return hip_status(fa2::launch_bwd_fused_bf16(a, (float*)acc, (int*)(acc + align256((size_t)B * H * seq_len * head_dim * 4)), 1,
+                                                         (hipStream_t)stream));
+        }
         return fa2_backward_block(Q, K, V, O, L, dO, dQ, dK, dV, B, H, seq_len, seq_len, head_dim, softmax_scale, dtype, 0, 0, 0,
                                   causal, 0, workspace, workspace_bytes, stream, phases);
+    }
     fa2::F32Args a{};
     a.Q = (const float*)Q; a.K = (const float*)K; a.V = (const float*)V; a.O = (float*)O;
     a.L = (float*)L; a.dO = (const float*)dO; a.dQ = (float*)dQ; a.dK = (float*)dK; a.dV = (float*)dV;
@@ -210,7 +250,7 @@ int fa2_backward_block(const void* Q, const void* K, const void* V, const void* 
     if (dtype != FA2_DTYPE_BF16) return FA2_ERR_UNSUPPORTED_DTYPE;
     st = check_dim(head_dim, dtype);
     if (st) return st;
-    if (!workspace || workspace_bytes < fa2_backward_workspace_bytes(B, H, q_hs, head_dim, dtype)) return FA2_ERR_WORKSPACE;
+    if (!workspace || workspace_bytes < bwd_base_ws(B, H, q_hs)) return FA2_ERR_WORKSPACE;
     fa2::BwdArgs a{};
     a.Q = Q; a.K = K; a.V = V; a.O = O; a.dO = dO; a.L = L; a.dQ = dQ; a.dK = dK; a.dV = dV;
     a.D = (float*)workspace; a.BH = B * H; a.Nq = q_len; a.Nk = kv_len; a.d = head_dim;
@@ -218,6 +258,32 @@ int fa2_backward_block(const void* Q, const void* K, const void* V, const void* 
     a.q_hs = q_hs; a.k_hs = k_hs; a.q_row0 = q_row0;
     a.scale = softmax_scale; a.causal = causal ? 1 : 0; a.causal_shift = causal ? causal_shift : 0; a.phases = phases & 7;
     return hip_status(fa2::launch_bwd_bf16(a, (hipStream_t)stream));
+}
+
+size_t fa2_backward_fused_workspace_bytes(int B, int H, int seq_len, int head_dim)
+{
+    if (B <= 0 || H <= 0 || seq_len <= 0 || !bwd_fused_shape(seq_len, head_dim, FA2_DTYPE_BF16)) return 0;
+    return fa2_backward_workspace_bytes(B, H, seq_len, head_dim, FA2_DTYPE_BF16);
+}
+
+int fa2_backward_fused(const void* Q, const void* K, const void* V, const void* O, const float* L,
+                       const void* dO, void* dQ, void* dK, void* dV,
+                       int B, int H, int seq_len, int head_dim, float softmax_scale, int mode,
+                       void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!Q || !K || !V || !O || !L || !dO || !dQ || !dK || !dV) return FA2_ERR_NULL_POINTER;
+    int st = check_common(B, H, seq_len, head_dim, softmax_scale);
+    if (st) return st;
+    if (!bwd_fused_shape(seq_len, head_dim, FA2_DTYPE_BF16) || (mode != 0 && mode != 1)) return FA2_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < fa2_backward_fused_workspace_bytes(B, H, seq_len, head_dim)) return FA2_ERR_WORKSPACE;
+    fa2::BwdArgs a{};
+    a.Q = Q; a.K = K; a.V = V; a.O = O; a.dO = dO; a.L = L; a.dQ = dQ; a.dK = dK; a.dV = dV;
+    a.D = (float*)workspace; a.BH = B * H; a.Nq = seq_len; a.Nk = seq_len; a.d = head_dim;
+    a.RC = (float*)((char*)workspace + align256((size_t)B * H * seq_len * sizeof(float)));
+    a.q_hs = seq_len; a.k_hs = seq_len; a.q_row0 = 0; a.scale = softmax_scale; a.causal = 0; a.causal_shift = 0; a.phases = 9;
+    char* acc = (char*)workspace + bwd_base_ws(B, H, seq_len);
+    return hip_status(fa2::launch_bwd_fused_bf16(a, (float*)acc, (int*)(acc + align256((size_t)B * H * seq_len * head_dim * 4)), mode,
+                                                 (hipStream_t)stream));
 }
 
 int fa2_forward_step(const void* Q, const void* K, const void* V,

@@ -98,22 +98,29 @@ int fa2_forward_fp8(const void* Q, const void* K, const void* V, void* O, float*
                     int B, int H, int seq_len, int head_dim, float softmax_scale, int causal,
                     void* workspace, size_t workspace_bytes, void* stream);
 
-/* Bytes of scratch fa2_backward needs for this problem (D vector, fp32 staging). */
+/* Bytes of scratch fa2_backward needs for this problem: D and the row-constant planes, plus -- for the shapes the
+ * single-kernel backward takes (bf16, head_dim 128, seq_len a multiple of 256) -- the fp32 running sums of dQ
+ * (B H seq_len head_dim 4 bytes) and a small control block. */
 size_t fa2_backward_workspace_bytes(int B, int H, int seq_len, int head_dim, int dtype);
 
-/* dQ, dK, dV from Q, K, V, O, L (forward outputs) and dO.  Deterministic: no atomics, every
- * gradient element is produced by exactly one workgroup in a fixed summation order (the
- * reference's smem + global atomicAdd scheme, flash_attention_backward_kernel.cu:208-231,
- * is not reproduced). */
+/* dQ, dK, dV from Q, K, V, O, L (forward outputs) and dO.  Deterministic: no floating-point atomics, every
+ * gradient element is summed in a fixed order (the reference's smem + global atomicAdd scheme,
+ * flash_attention_backward_kernel.cu:208-231, is not reproduced).  Two implementations behind this call:
+ *   - bf16, head_dim 128, non-causal, seq_len a multiple of 256: ONE kernel that forms the five block products once
+ *     (csrc/fa2_bwd_fused.hip); a workgroup owns 256 keys (dK, dV in registers) and the dQ tiles are summed key block
+ *     after key block in a fixed order through the L2 of the XCD the head is pinned to;
+ *   - everything else: a dQ kernel and a dK/dV kernel (seven products, csrc/fa2_bwd_bf16.hip).
+ * The environment variable FA2_BACKWARD_PATH=two_kernel keeps every shape on the second form. */
 int fa2_backward(const void* Q, const void* K, const void* V, const void* O, const float* L,
                  const void* dO, void* dQ, void* dK, void* dV,
                  int B, int H, int seq_len, int head_dim, float softmax_scale,
                  int dtype, int causal, void* workspace, size_t workspace_bytes, void* stream);
 
-/* The same, restricted to some of its three kernels -- bit 0: D = rowsum(dO o O) into the
- * workspace, bit 1: dQ, bit 2: dK and dV (7 = fa2_backward).  For profiling and for callers
- * that overlap the two independent main kernels on separate streams; bits 1 and 2 need the
- * D that bit 0 produced in the same workspace. */
+/* The same, restricted to some of its kernels -- bit 0: D = rowsum(dO o O) and the row constants into the
+ * workspace, bit 1: the dQ kernel, bit 2: the dK/dV kernel, bit 3: the single five-product kernel and its output
+ * pass (FA2_ERR_UNSUPPORTED for shapes it does not take).  7 = fa2_backward (which picks the implementation);
+ * 6 = the two-kernel form whatever the shape.  For profiling and for callers that overlap the two independent
+ * kernels on separate streams; bits 1, 2 and 3 need what bit 0 produced in the same workspace. */
 int fa2_backward_phases(const void* Q, const void* K, const void* V, const void* O, const float* L,
                         const void* dO, void* dQ, void* dK, void* dV,
                         int B, int H, int seq_len, int head_dim, float softmax_scale,
@@ -136,6 +143,17 @@ int fa2_backward_block(const void* Q, const void* K, const void* V, const void* 
                        int B, int H, int q_len, int kv_len, int head_dim, float softmax_scale, int dtype,
                        int q_head_stride, int kv_head_stride, int q_row0, int causal, int causal_shift,
                        void* workspace, size_t workspace_bytes, void* stream, int phases);
+
+/* The single-kernel five-product backward (csrc/fa2_bwd_fused.hip) with the way dQ is summed over the key-block
+ * workgroups of a head chosen by the caller -- mode 1: handed from key block to key block in a fixed order by a
+ * persistent grid (deterministic; what fa2_backward uses), mode 0: fp32 atomics (NOT bit-reproducible; kept as the
+ * measured alternative).  bf16, d = 128, non-causal, seq_len a multiple of 256;
+ * FA2_ERR_UNSUPPORTED otherwise.  Workspace: fa2_backward_fused_workspace_bytes (= fa2_backward_workspace_bytes). */
+size_t fa2_backward_fused_workspace_bytes(int B, int H, int seq_len, int head_dim);
+int fa2_backward_fused(const void* Q, const void* K, const void* V, const void* O, const float* L,
+                       const void* dO, void* dQ, void* dK, void* dV,
+                       int B, int H, int seq_len, int head_dim, float softmax_scale, int mode,
+                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* One resumable forward step: folds the kv_len keys/values of a resident shard into the running
  * state of q_len local query rows -- the unit of work of ring_attention_forward_kernel

@@ -1,0 +1,165 @@
+"""GPU: the single-kernel (five-product) backward of csrc/fa2_bwd_fused.hip, through the C ABI.
+
+fa2_backward takes it for bf16, head_dim 128, non-causal, seq_len % 256 == 0; everything else stays on the dQ and dK/dV
+kernels.  Checked here:
+  * against the CPU oracle (rel-L2 <= 5e-3 per tensor, the bf16 bar of test_gpu_parity.py), for both ways of summing dQ
+    over the key blocks (mode 1: ordered hand-off -- what fa2_backward uses; mode 0: fp32 atomics);
+  * dK and dV BIT-EQUAL to the two-kernel backward (same products in the same order), dQ within bf16 rounding of it
+    (a different, but fixed, summation order);
+  * mode 1 is bit-reproducible run to run (no floating-point atomics; the order of the additions is fixed);
+  * chains longer than an XCD has CUs (seq_len 16384: 64 key blocks), head counts that are not a multiple of the XCD count,
+    more heads than the grid has workgroups;
+  * the dispatch of fa2_backward / fa2_backward_phases and the status codes of the explicit entry point."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+BF16_REL = 5e-3
+
+
+def _fa():
+    import cuda_flashattention_amd as fa
+    return fa
+
+
+def rel(a, b):
+    return float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def f32(t):
+    return t.float().cpu().numpy()
+
+
+def make(B, H, N, d, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return ((torch.rand(B, H, N, d, generator=g) - 0.5) * scale).to(torch.bfloat16)
+
+
+P = lambda t: ctypes.c_void_p(t.data_ptr())
+
+
+def fused(Q, K, V, O, L, dO, scale, mode, ws=None):
+    lib = _fa()._capi.lib()
+    B, H, N, d = Q.shape
+    dQ, dK, dV = torch.empty_like(Q), torch.empty_like(Q), torch.empty_like(Q)
+    nb = lib.fa2_backward_fused_workspace_bytes(B, H, N, d)
+    assert nb == lib.fa2_backward_workspace_bytes(B, H, N, d, 0) > 0
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda") if ws is None else ws
+    st = lib.fa2_backward_fused(P(Q), P(K), P(V), P(O), P(L), P(dO), P(dQ), P(dK), P(dV), B, H, N, d, scale, mode, P(ws), nb,
+                                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert st == 0, st
+    return dQ, dK, dV
+
+
+def case(B, H, N, seed=0):
+    d = 128
+    Q, K, V, dO = make(B, H, N, d, seed), make(B, H, N, d, seed + 1), make(B, H, N, d, seed + 2), make(B, H, N, d, seed + 3, 0.4)
+    scale = 1.0 / d ** 0.5
+    dev = [t.cuda() for t in (Q, K, V, dO)]
+    O, L = _fa().flash_attention_2_forward(dev[0], dev[1], dev[2], scale)
+    return (Q, K, V, dO), dev, O, L, scale
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+@pytest.mark.parametrize("B,H,N", [
+    (1, 1, 256),       # one key block: no hand-off at all
+    (1, 2, 512),
+    (2, 8, 1024),
+    (1, 3, 768),       # 3 heads: not a multiple of the XCD count
+    (1, 9, 2048),
+    (1, 70, 256),      # more heads than one round of the per-XCD queues
+])
+def test_fused_backward_vs_oracle(B, H, N, mode):
+    import oracle
+    host, dev, O, L, scale = case(B, H, N, seed=11 * N + H)
+    got = fused(dev[0], dev[1], dev[2], O, L, dev[3], scale, mode)
+    torch.cuda.synchronize()
+    want = oracle.attention_backward(*[f32(t) for t in host], scale)
+    for name, g, w in zip(("dQ", "dK", "dV"), got, want):
+        assert np.isfinite(f32(g)).all(), name
+        assert rel(f32(g), w) <= BF16_REL, (name, rel(f32(g), w))
+
+
+def test_fa2_backward_takes_the_fused_kernel_and_matches_the_two_kernel_form():
+    """fa2_backward (phases 7) on an eligible shape == fa2_backward_fused(mode 1) bit for bit; its dK, dV == the two-kernel
+    form (phases 6 after phase 1) bit for bit, its dQ within bf16 rounding of that form's."""
+    fa = _fa()
+    host, dev, O, L, scale = case(2, 5, 1024, seed=5)
+    a = fa.flash_attention_2_backward(dev[0], dev[1], dev[2], O, L, dev[3], scale)
+    b = fused(dev[0], dev[1], dev[2], O, L, dev[3], scale, 1)
+    c = [torch.empty_like(dev[0]) for _ in range(3)]
+    ws = torch.empty(fa._capi.lib().fa2_backward_workspace_bytes(2, 5, 1024, 128, 0), dtype=torch.uint8, device="cuda")
+    fa.flash_attention_2_backward(dev[0], dev[1], dev[2], O, L, dev[3], scale, dQ=c[0], dK=c[1], dV=c[2], workspace=ws, phases=1)
+    fa.flash_attention_2_backward(dev[0], dev[1], dev[2], O, L, dev[3], scale, dQ=c[0], dK=c[1], dV=c[2], workspace=ws, phases=6)
+    torch.cuda.synchronize()
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert torch.equal(a[1], c[1]) and torch.equal(a[2], c[2])
+    assert rel(f32(a[0]), f32(c[0]).astype(np.float64)) <= 1e-3
+
+
+def test_ordered_handoff_is_bit_reproducible_and_long_chains_work():
+    """seq_len 16384 = 64 key blocks per head, twice the CUs of an XCD: workgroups take a second unit of the same head, whose
+    first sub-tiles the chain's tail is still waiting for.  Rows sampled against the oracle's row-wise backward are too slow
+    here; the two-kernel form (itself oracle-checked at this length in test_gpu_parity.py) is the reference."""
+    fa = _fa()
+    B, H, N, d = 1, 2, 16384, 128
+    g = torch.Generator(device="cuda").manual_seed(3)
+    mk = lambda s: ((torch.rand(B, H, N, d, device="cuda", generator=g) - 0.5) * s).bfloat16()
+    Q, K, V, dO = mk(1), mk(1), mk(1), mk(0.4)
+    scale = d ** -0.5
+    O, L = fa.flash_attention_2_forward(Q, K, V, scale)
+    ws = torch.empty(fa._capi.lib().fa2_backward_workspace_bytes(B, H, N, d, 0), dtype=torch.uint8, device="cuda")
+    r1 = fused(Q, K, V, O, L, dO, scale, 1, ws)
+    ws.fill_(0x5a)                                        # stale running sums / flags from an earlier launch must not matter
+    r2 = fused(Q, K, V, O, L, dO, scale, 1, ws)
+    two = [torch.empty_like(Q) for _ in range(3)]
+    fa.flash_attention_2_backward(Q, K, V, O, L, dO, scale, dQ=two[0], dK=two[1], dV=two[2], workspace=ws, phases=1)
+    fa.flash_attention_2_backward(Q, K, V, O, L, dO, scale, dQ=two[0], dK=two[1], dV=two[2], workspace=ws, phases=6)
+    torch.cuda.synchronize()
+    for x, y in zip(r1, r2):
+        assert torch.equal(x, y)
+    assert torch.equal(r1[1], two[1]) and torch.equal(r1[2], two[2])
+    assert rel(f32(r1[0]), f32(two[0]).astype(np.float64)) <= 1e-3
+
+
+def test_bench_shape_matches_the_two_kernel_form():
+    """(4, 16, 8192, 128), the headline shape: 2048 units over a persistent grid of one workgroup per CU."""
+    fa = _fa()
+    B, H, N, d = 4, 16, 8192, 128
+    g = torch.Generator(device="cuda").manual_seed(8)
+    mk = lambda s: ((torch.rand(B, H, N, d, device="cuda", generator=g) - 0.5) * s).bfloat16()
+    Q, K, V, dO = mk(1), mk(1), mk(1), mk(0.4)
+    O, L = fa.flash_attention_2_forward(Q, K, V)
+    ws = torch.empty(fa._capi.lib().fa2_backward_workspace_bytes(B, H, N, d, 0), dtype=torch.uint8, device="cuda")
+    a = [torch.empty_like(Q) for _ in range(3)]
+    b = [torch.empty_like(Q) for _ in range(3)]
+    fa.flash_attention_2_backward(Q, K, V, O, L, dO, dQ=a[0], dK=a[1], dV=a[2], workspace=ws)
+    fa.flash_attention_2_backward(Q, K, V, O, L, dO, dQ=b[0], dK=b[1], dV=b[2], workspace=ws, phases=1)
+    fa.flash_attention_2_backward(Q, K, V, O, L, dO, dQ=b[0], dK=b[1], dV=b[2], workspace=ws, phases=6)
+    torch.cuda.synchronize()
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert float((a[0].float() - b[0].float()).norm() / b[0].float().norm()) <= 1e-3
+
+
+def test_status_codes():
+    lib = _fa()._capi.lib()
+    x = torch.zeros(1, 1, 256, 128, dtype=torch.bfloat16, device="cuda")
+    l = torch.zeros(1, 1, 256, device="cuda")
+    ws = torch.empty(lib.fa2_backward_workspace_bytes(1, 1, 256, 128, 0), dtype=torch.uint8, device="cuda")
+    call = lambda N, d, mode, nb: lib.fa2_backward_fused(P(x), P(x), P(x), P(x), P(l), P(x), P(x), P(x), P(x), 1, 1, N, d, 0.1, mode,
+                                                         P(ws), nb, None)
+    assert lib.fa2_backward_fused_workspace_bytes(1, 1, 300, 128) == 0
+    assert lib.fa2_backward_fused_workspace_bytes(1, 1, 256, 64) == 0
+    assert call(300, 128, 1, ws.numel()) != 0          # not a multiple of 256
+    assert call(256, 64, 1, ws.numel()) != 0           # head_dim 64
+    assert call(256, 128, 2, ws.numel()) != 0          # no such mode
+    assert call(256, 128, 1, 1024) != 0                # workspace too small
+    # bit 3 of fa2_backward_phases on a shape the single kernel does not take
+    st = lib.fa2_backward_phases(P(x), P(x), P(x), P(x), P(l), P(x), P(x), P(x), P(x), 1, 1, 256, 128, 0.1, 0, 1, P(ws), ws.numel(), None, 8)
+    assert st != 0                                     # causal

@@ -27,7 +27,7 @@ CSRC = os.path.join(ROOT, "cuda_flashattention_amd", "csrc")
 def asm():
     subprocess.check_call(["make", "-s", "-j", "4", "-C", CSRC, "asm"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     out = {}
-    for f in ("fa2_fwd_bf16", "fa2_bwd_bf16", "fa2_fwd_fp8", "fa2_f32", "fa2_util", "fa1_f32"):
+    for f in ("fa2_fwd_bf16", "fa2_bwd_bf16", "fa2_bwd_fused", "fa2_fwd_fp8", "fa2_f32", "fa2_util", "fa1_f32"):
         out[f] = open(os.path.join(CSRC, "_obj", f + ".s")).read()
     return out
 
@@ -79,7 +79,7 @@ def _main_loop(body):
     return body[lo:hi]
 
 
-PRODUCT = ("fa2_fwd_bf16", "fa2_bwd_bf16", "fa2_fwd_fp8", "fa2_f32", "fa2_util", "fa1_f32")
+PRODUCT = ("fa2_fwd_bf16", "fa2_bwd_bf16", "fa2_bwd_fused", "fa2_fwd_fp8", "fa2_f32", "fa2_util", "fa1_f32")
 
 
 def test_no_scratch_no_spill(asm):
@@ -94,7 +94,7 @@ def test_no_scratch_no_spill(asm):
 
 
 @pytest.mark.parametrize("file,pattern", [("fa2_fwd_bf16", "fa2_fwd_bf16_kernel"), ("fa2_bwd_bf16", "fa2_bwd_dq_kernel"),
-                                          ("fa2_bwd_bf16", "fa2_bwd_dkdv_kernel")])
+                                          ("fa2_bwd_bf16", "fa2_bwd_dkdv_kernel"), ("fa2_bwd_fused", "fa2_bwd_fused_kernelILb")])
 def test_accumulator_file_is_touched_by_asm_only(asm, file, pattern):
     """The kernels that name literal AGPRs: nothing hipcc generates may read, write, copy or spill an accumulator."""
     ks = {n: k for n, k in _kernels(asm[file]).items() if pattern in n}
@@ -123,6 +123,39 @@ def test_named_vgprs_are_the_bodies_own(asm, pattern, limit, top128, top64):
         assert k["meta"]["total"] == 512 and k["meta"]["agpr"] == 256, (name, k["meta"])
         used = max(int(m.group(1) or m.group(3)) for b in blocks for s in b for m in pat.finditer(s))
         assert used == (top128 if "ILi128E" in name else top64), (name, used)      # VEND - 1 of the generator
+
+
+def test_fused_backward_kernel(asm):
+    """The single-kernel backward is compiled with amdgpu_num_vgpr(39): v39 is the kernel's own prefetch register, v40..v255
+    belong to the generated body (tools/gen_fused_body.py).  Its hot loop holds six bodies of 80 MFMAs (ring of three Q/dO
+    buffers x two dS tiles), the chained form's bodies carry their four dQ stores in front of the barrier and the four
+    running-sum loads behind it, and nothing in the loop touches scratch."""
+    ks = {n: k for n, k in _kernels(asm["fa2_bwd_fused"]).items() if "fa2_bwd_fused_kernelILb" in n}
+    assert len(ks) == 2
+    pat = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+    for name, k in ks.items():
+        chain = "ILb1E" in name
+        outside, blocks = _split_asm(k["body"])
+        for s in outside:
+            for m in pat.finditer(s):
+                hi = int(m.group(1)) if m.group(1) else int(m.group(3))
+                assert hi < 39, (name, s)
+        assert k["meta"]["total"] == 512 and k["meta"]["agpr"] == 256, (name, k["meta"])
+        loop = _main_loop(k["body"])
+        assert sum("v_mfma_f32_32x32x16_bf16" in l for l in loop) == 6 * 80, name
+        assert not any("scratch_" in l for l in loop), name
+        bodies = [b for b in _split_asm(loop)[1] if sum("v_mfma" in s for s in b) == 80]
+        assert len(bodies) == 6
+        for b in bodies:
+            st = [i for i, s in enumerate(b) if s.startswith("buffer_store_dwordx4")]
+            ld = [i for i, s in enumerate(b) if s.startswith("buffer_load_dwordx4")]
+            bar = [i for i, s in enumerate(b) if s.startswith("s_barrier")]
+            assert len(bar) == 1 and b[bar[0] - 1].startswith("s_waitcnt vmcnt(0)")
+            if chain:
+                assert len(st) == 4 and len(ld) == 4 and max(st) < bar[0] < min(ld), name
+                assert all(" sc1" in b[i] for i in ld)
+            else:
+                assert not st and not ld
 
 
 def test_forward_loop_shape(asm):
@@ -167,7 +200,7 @@ def test_fp8_loop_budget(asm):
             assert any("v_mfma_f32_32x32x64_f8f6f4" in l for l in _main_loop(k["body"]))
 
 
-@pytest.mark.parametrize("inc", ["fa2_bwd_dkdv_body.inc", "fa2_bwd_dq_body.inc"])
+@pytest.mark.parametrize("inc", ["fa2_bwd_dkdv_body.inc", "fa2_bwd_dq_body.inc", "fa2_bwd_fused_body.inc"])
 def test_generated_bodies_pass_the_static_checker(inc):
     """tools/check_body.py replays every generated main-loop body twice in a row (steady state) with an in-order model of
     the LDS queue: each MFMA source delivered by an LDS read is covered by a counted lgkmcnt, no read overwrites a
@@ -178,7 +211,7 @@ def test_generated_bodies_pass_the_static_checker(inc):
     cb = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(cb)
     text = open(os.path.join(CSRC, inc)).read()
-    names = re.findall(r"#define (FA2_\w+_BODY_\w+) ", text)
+    names = re.findall(r"#define (FA2_\w+_C?BODY_\w+) ", text)
     assert len(names) in (12, 16)
     for n in names:
         assert cb.check(cb.body(text, n), n) == []
@@ -186,7 +219,8 @@ def test_generated_bodies_pass_the_static_checker(inc):
 
 def test_generated_bodies_are_up_to_date(tmp_path):
     """The committed .inc files are what the generators produce (nobody edits them by hand, nobody forgets to regenerate)."""
-    for gen, inc in (("gen_dkdv_body.py", "fa2_bwd_dkdv_body.inc"), ("gen_dq_body.py", "fa2_bwd_dq_body.inc")):
+    for gen, inc in (("gen_dkdv_body.py", "fa2_bwd_dkdv_body.inc"), ("gen_dq_body.py", "fa2_bwd_dq_body.inc"),
+                     ("gen_fused_body.py", "fa2_bwd_fused_body.inc")):
         out = tmp_path / inc
         subprocess.check_call(["python3", os.path.join(ROOT, "tools", gen), "--out", str(out)], cwd=os.path.join(ROOT, "tools"),
                               stdout=subprocess.DEVNULL)

@@ -33,6 +33,7 @@ def check(lines, label):
     errs = []
     queue = []                 # outstanding LDS reads: (dst regs)
     pending = {}               # reg -> True while an LDS read into it is outstanding
+    vm_pending = {}            # reg -> True while a buffer load into it is outstanding
     mfma_no = 0
     mfma_wrote = {}            # reg -> mfma index that last wrote it
     valu_wrote = {}            # reg -> instruction index
@@ -46,6 +47,8 @@ def check(lines, label):
                 continue
             op = toks[0]
             if op == "s_waitcnt":
+                if "vmcnt" in l:               # every vmcnt wait in these bodies covers the body's own buffer loads
+                    vm_pending.clear()
                 m = re.search(r"lgkmcnt\((\d+)\)", l)
                 if m:
                     n = int(m.group(1))
@@ -60,11 +63,32 @@ def check(lines, label):
                     frag_consumed[r] = False
                     pending[r] = True
                 queue.append(dst)
+            elif op.startswith("ds_write"):
+                queue.append(set())          # LDS writes share lgkmcnt with the reads and complete in order with them
+                for t in toks[2:3]:
+                    for r in regs(t):
+                        if r in pending and rep == 1:
+                            errs.append(f"{label}: line {i}: {l}  stores v{r} while an LDS read into it is in flight")
+            elif op.startswith("buffer_store"):
+                for r in regs(toks[1]):
+                    if r in pending and rep == 1:
+                        errs.append(f"{label}: line {i}: {l}  stores v{r} while an LDS read into it is in flight")
+                    if r in vm_pending and rep == 1:
+                        errs.append(f"{label}: line {i}: {l}  stores v{r} while a buffer load into it is in flight")
+                    if r in mfma_wrote and mfma_no - 1 - mfma_wrote[r] < PASS_GAP and rep == 1:
+                        errs.append(f"{label}: line {i}: {l}  stores v{r} only {mfma_no - 1 - mfma_wrote[r]} MFMAs after the MFMA that writes it")
+            elif op.startswith("buffer_load"):
+                for r in regs(toks[1]):
+                    if r in last_read_by_mfma and mfma_no - 1 - last_read_by_mfma[r] < 1 and rep == 1:
+                        errs.append(f"{label}: line {i}: {l}  loads into v{r} right behind the MFMA that reads it")
+                    vm_pending[r] = True
             elif op.startswith("v_mfma"):
                 dst, a, b, c = (regs(t) for t in toks[1:5])
                 for r in a | b | c:
                     if r in pending and rep == 1:
                         errs.append(f"{label}: line {i}: {l}  reads v{r} before its LDS read is waited for")
+                    if r in vm_pending and rep == 1:
+                        errs.append(f"{label}: line {i}: {l}  reads v{r} before its buffer load is waited for")
                     if r in valu_wrote and idx - valu_wrote[r] < 2 and rep == 1:
                         errs.append(f"{label}: line {i}: {l}  reads v{r} {idx - valu_wrote[r]} instruction(s) after a VALU write")
                     frag_consumed[r] = True
@@ -88,7 +112,7 @@ def check(lines, label):
 
 def main():
     text = open(sys.argv[1]).read()
-    names = sys.argv[2:] or re.findall(r"#define (FA2_\w+_BODY_\w+) ", text)
+    names = sys.argv[2:] or re.findall(r"#define (FA2_\w+_C?BODY_\w+) ", text)
     bad = 0
     for n in names:
         e = check(body(text, n), n)

@@ -1,0 +1,316 @@
+#!/usr/bin/env python3
+"""Generates the main-loop body of the FUSED five-product backward prototype -> csrc/fa2_bwd_fused_body.inc.
+
+One workgroup = 4 waves = 256 keys of one head (as in fa2_bwd_dkdv_kernel), but the query gradient is formed here too:
+per 32-row sub-tile and wave
+
+    A  S'  = Q K^T - L/scale         2 x 8 MFMAs     K fragments from the K IMAGE in LDS (V moved to resident VGPRs)
+    B  dP' = dO V^T - D              2 x 8 MFMAs
+    E  dQ[q][col] += dS[q][key] K[key][col] of the PREVIOUS sub-tile: 16 MFMAs over all 256 keys of the workgroup for
+       this wave's 32 columns -- dS crosses LDS once ([key][q] tile written as the packed pairs already are, read back
+       transposed), K^T comes from the same K image by transposed reads
+    C  dV^T += dO^T P                16 MFMAs
+    D  dK^T += Q^T dS                16 MFMAs        then the packed dS pairs are written to the dS tile
+
+Five block products (80 MFMAs per sub-tile) instead of the seven of the two-kernel backward.  Q/dO tiles of 32 rows live in
+a ring of three LDS buffers, the dS tile is double buffered, one barrier per sub-tile (in front of the first read of the
+next tile: vmcnt(0) covers the DMA and this wave's dQ stores, the barrier makes everyone's dS visible).
+
+Registers (kernel compiled with amdgpu_num_vgpr(40)): a[0:128) dK^T, a[128:256) dV^T;
+    v[40:104) V fragments vf[kb][s]; SACC, DPACC, PF, DSF as in the dK/dV kernel; six fragment slots; DQT = 16 registers
+    holding this wave's dQ tile (the E chain accumulates on top of what the kernel put there: zeros, or the running sum
+    handed over by the previous key block's workgroup); ROFFK (8: row-read addresses of the wave's K rows), DSWR (4: dS
+    write addresses), DSRD (2), KT (2).
+Two families: FA2_FUSED_BODY_* (the dQ tile is left in DQT for the kernel) and FA2_FUSED_CBODY_* (chained kernel: the body
+itself stores the finished tile and loads the next running sum; extra operands %[dqv], %[drs], %[dso], %[lrs], %[lso]).
+Operands: %[r*], %[t*] (Q/dO ring addresses), %[rc], %[c2], %[vm] (immediate: how many of the kernel's vector-memory
+operations may still be in flight when the E chain starts -- those issued after its loads into DQT; 63 = no such loads).
+Same generator core as tools/gen_dkdv_body.py (cyclic bodies, counted waits derived from the issue order)."""
+import argparse
+import os
+import re
+
+import gen_dkdv_body as base
+from gen_dkdv_body import Task, COST, READ_AHEAD, READ_LATEST
+
+D, KS, DT = 128, 8, 4
+ROWB = 2 * D
+NSLOT = 6
+V0 = 40
+VF, SACC, DPACC, PF, DSF, SLOT = V0, V0 + 64, V0 + 96, V0 + 128, V0 + 144, V0 + 160
+DQT = SLOT + 4 * NSLOT            # 224
+ROFFK = DQT + 16                  # 240
+DSWR = ROFFK + 8                  # 248..251
+DSRD = DSWR + 4                   # 252, 253
+KT = DSRD + 2                     # 254, 255
+assert KT + 2 == 256
+A_DK, A_DV = 0, 128
+# LDS map (bytes)
+KIMG = 0
+QRING = 65536
+BUFB = 2 * 32 * ROWB + 256        # Q tile | dO tile | 32 x (-L/scale), 32 x (-D)
+DSB = QRING + 3 * BUFB            # two dS tiles of 256 keys x 32 q bf16
+DSTILE = 256 * 64
+LDS_BYTES = DSB + 2 * DSTILE
+COST = dict(COST, ldsw=6, vmem=10)
+
+
+def vf(kb, s): b = VF + 4 * (kb * KS + s); return f"v[{b}:{b + 3}]"
+def sacc(kb): b = SACC + 16 * kb; return f"v[{b}:{b + 15}]"
+def sreg(kb, r): return f"v{SACC + 16 * kb + r}"
+def dpacc(kb): b = DPACC + 16 * kb; return f"v[{b}:{b + 15}]"
+def dreg(kb, r): return f"v{DPACC + 16 * kb + r}"
+def pf(kb, sp): b = PF + 4 * (2 * kb + sp); return f"v[{b}:{b + 3}]"
+def pfw(kb, sp, j): return f"v{PF + 4 * (2 * kb + sp) + j}"
+def dsf(kb, sp): b = DSF + 4 * (2 * kb + sp); return f"v[{b}:{b + 3}]"
+def dsfw(kb, sp, j): return f"v{DSF + 4 * (2 * kb + sp) + j}"
+def slot(i): b = SLOT + 4 * i; return f"v[{b}:{b + 3}]"
+def slot_lo(i): b = SLOT + 4 * i; return f"v[{b}:{b + 1}]"
+def slot_hi(i): b = SLOT + 4 * i + 2; return f"v[{b}:{b + 1}]"
+def dk(kb, dt): b = A_DK + 16 * (kb * DT + dt); return f"a[{b}:{b + 15}]"
+def dv(kb, dt): b = A_DV + 16 * (kb * DT + dt); return f"a[{b}:{b + 15}]"
+DQTILE = f"v[{DQT}:{DQT + 15}]"
+
+
+def build(chain=False):
+    NS = 80
+    gA1, gB, gE, gC, gD = KS + 1, 16, 32, 48, 64
+    mfma = [None] * NS
+    tasks = []
+    ctr = [0]
+    busy = [-(10 ** 6)] * NSLOT
+
+    def take(last):
+        i = ctr[0] % NSLOT
+        ctr[0] += 1
+        f = busy[i]
+        busy[i] = last
+        return i, f
+
+    def rd(text, key, consume, free_after):
+        rel = max(consume - READ_AHEAD, free_after + 1)
+        tasks.append(Task(text, COST["lds"], rel, max(consume - READ_LATEST, rel), "lds", key))
+
+    def allocate(rec):
+        # ---- A0 / A1 (as in the dK/dV kernel, with K fragments from the K image)
+        sq, fq = take(1)
+        s1, f1 = take(0)
+        s0, f0 = take(1)
+        if rec:
+            rd(f"ds_read_b128 {slot(sq)}, %[r0] offset:@Q+0", ("Q", 0, 0), 0, fq)
+            rd(f"ds_read_b128 {slot(s1)}, v{ROFFK} offset:{32 * ROWB}", ("K", 1, 0), 0, f1)
+            rd(f"ds_read_b128 {slot(s0)}, v{ROFFK}", ("K", 0, 0), 1, f0)
+            mfma[0] = (f"v_mfma_f32_32x32x16_bf16 {sacc(1)}, {slot(sq)}, {slot(s1)}, {sacc(0)}", [("Q", 0, 0), ("K", 1, 0), ("RCS",)])
+            mfma[1] = (f"v_mfma_f32_32x32x16_bf16 {sacc(0)}, {slot(sq)}, {slot(s0)}, {sacc(0)}", [("Q", 0, 0), ("K", 0, 0)])
+        for kb in (0, 1):
+            for s in range(1, KS):
+                g = (1 + s) if kb == 0 else (gA1 + s - 1)
+                a, fa = take(g)
+                b, fb = take(g)
+                if rec:
+                    rd(f"ds_read_b128 {slot(a)}, %[r{s}] offset:@Q+0", ("Q", kb, s), g, fa)
+                    rd(f"ds_read_b128 {slot(b)}, v{ROFFK + s} offset:{kb * 32 * ROWB}", ("K", kb, s), g, fb)
+                    mfma[g] = (f"v_mfma_f32_32x32x16_bf16 {sacc(kb)}, {slot(a)}, {slot(b)}, {sacc(kb)}", [("Q", kb, s), ("K", kb, s)])
+        # ---- B: dP' (dO fragment shared by the two key blocks; V fragments are resident)
+        for s in range(KS):
+            g = gB + 2 * s
+            sg, fg = take(g + 1)
+            if rec:
+                rd(f"ds_read_b128 {slot(sg)}, %[r{s}] offset:@G+0", ("G", s), g, fg)
+                if s == 0:
+                    mfma[g] = (f"v_mfma_f32_32x32x16_bf16 {dpacc(1)}, {slot(sg)}, {vf(1, s)}, {dpacc(0)}", [("G", s), ("RCD",)])
+                    mfma[g + 1] = (f"v_mfma_f32_32x32x16_bf16 {dpacc(0)}, {slot(sg)}, {vf(0, s)}, {dpacc(0)}", [("G", s)])
+                else:
+                    mfma[g] = (f"v_mfma_f32_32x32x16_bf16 {dpacc(0)}, {slot(sg)}, {vf(0, s)}, {dpacc(0)}", [("G", s)])
+                    mfma[g + 1] = (f"v_mfma_f32_32x32x16_bf16 {dpacc(1)}, {slot(sg)}, {vf(1, s)}, {dpacc(1)}", [("G", s)])
+        # ---- E: dQ of the previous sub-tile: 16 k-steps of 16 keys over the workgroup's 256 keys.  The K^T fragments go
+        # through the regular slots; the dS fragments land in the four DSF tuples, which are idle from the previous body's D
+        # stage to this body's dS packs (so E reads five MFMAs ahead instead of three).
+        xbusy = [gD - NS + 6, gD - NS + 7, gD - NS + 14, gD - NS + 15]      # last D-stage readers of dsf(0,0), (1,0), (0,1), (1,1)
+        for s in range(16):
+            g = gE + s
+            x = s % 4
+            xr = DSF + 4 * x
+            sb, fb = take(g)
+            fa = xbusy[x]
+            xbusy[x] = g
+            if rec:
+                ka, kb_ = ("DS", s), ("KT", s)
+                rd(f"ds_read_b64_tr_b16 v[{xr}:{xr + 1}], v{DSRD} offset:@DSP+{1024 * s}", ("ds0", s), g, fa)
+                rd(f"ds_read_b64_tr_b16 v[{xr + 2}:{xr + 3}], v{DSRD + 1} offset:@DSP+{1024 * s}", ka, g, fa)
+                rd(f"ds_read_b64_tr_b16 {slot_lo(sb)}, v{KT} offset:{16 * ROWB * s}", ("kt0", s), g, fb)
+                rd(f"ds_read_b64_tr_b16 {slot_hi(sb)}, v{KT + 1} offset:{16 * ROWB * s}", kb_, g, fb)
+                mfma[g] = (f"v_mfma_f32_32x32x16_bf16 {DQTILE}, v[{xr}:{xr + 3}], {slot(sb)}, {DQTILE}", [ka, kb_, ("ds0", s), ("kt0", s)])
+        # ---- C, D
+        for nm, basep, gs, acc, frag in (("GT", "@G", gC, dv, pf), ("QT", "@Q", gD, dk, dsf)):
+            for sp in (0, 1):
+                for dt in range(DT):
+                    g = gs + 2 * (sp * DT + dt)
+                    sl, fr = take(g + 1)
+                    if rec:
+                        ka, kb_ = (nm, sp, dt, 0), (nm, sp, dt, 1)
+                        rd(f"ds_read_b64_tr_b16 {slot_lo(sl)}, %[t{2 * dt}] offset:{basep}+{sp * 16 * ROWB}", ka, g, fr)
+                        rd(f"ds_read_b64_tr_b16 {slot_hi(sl)}, %[t{2 * dt + 1}] offset:{basep}+{sp * 16 * ROWB}", kb_, g, fr)
+                        mfma[g] = (f"v_mfma_f32_32x32x16_bf16 {acc(0, dt)}, {slot(sl)}, {frag(0, sp)}, {acc(0, dt)}", [ka, kb_])
+                        mfma[g + 1] = (f"v_mfma_f32_32x32x16_bf16 {acc(1, dt)}, {slot(sl)}, {frag(1, sp)}, {acc(1, dt)}", [ka, kb_])
+        while ctr[0] % NSLOT:
+            take(NS - 1)                          # skipped slot numbers: the rotation closes over a sub-tile
+
+    allocate(False)
+    for i in range(NSLOT):
+        busy[i] -= NS
+    ctr[0] = 0
+    allocate(True)
+
+    def valu(text, kind, rel, dl, after=None):
+        t = Task(text, COST[kind], rel, dl, kind, after=after)
+        tasks.append(t)
+        return t
+
+    last_p, last_d = {}, {}
+    for kb in (0, 1):
+        rel_exp = (KS if kb == 0 else 2 * KS - 1) + 3
+        exps = {}
+        for sp in (0, 1):
+            use_pf = gC + 2 * sp * DT + kb
+            for j in range(4):
+                pair = []
+                for r in (8 * sp + 2 * j, 8 * sp + 2 * j + 1):
+                    m = valu(f"v_mul_f32 {sreg(kb, r)}, %[c2], {sreg(kb, r)}", "valu", rel_exp, use_pf - 5)
+                    e = valu(f"v_exp_f32 {sreg(kb, r)}, {sreg(kb, r)}", "exp", rel_exp, use_pf - 4, after=[m])
+                    exps[r] = e
+                    pair.append(e)
+                valu(f"v_cvt_pk_bf16_f32 {pfw(kb, sp, j)}, {sreg(kb, 8 * sp + 2 * j)}, {sreg(kb, 8 * sp + 2 * j + 1)}", "cvt", rel_exp,
+                     use_pf - 2, after=pair)
+        rel_ds = gB + 2 * (KS - 1) + kb + 3
+        for sp in (0, 1):
+            use_ds = gD + 2 * sp * DT + kb
+            for jp in (0, 1):
+                cv = []
+                for j in (2 * jp, 2 * jp + 1):
+                    pair = []
+                    for r in (8 * sp + 2 * j, 8 * sp + 2 * j + 1):
+                        t = valu(f"v_mul_f32 {dreg(kb, r)}, {sreg(kb, r)}, {dreg(kb, r)}", "valu", rel_ds, use_ds - 3, after=[exps[r]])
+                        pair.append(t)
+                        last_p[kb] = t
+                    c = valu(f"v_cvt_pk_bf16_f32 {dsfw(kb, sp, j)}, {dreg(kb, 8 * sp + 2 * j)}, {dreg(kb, 8 * sp + 2 * j + 1)}", "cvt",
+                             max(rel_ds, gC), use_ds - 2, after=pair)       # the DSF tuples are E's dS fragment slots until E ends
+                    cv.append(c)
+                    last_d[kb] = c
+                # the packed pair (4 consecutive q of this lane's key) -> the dS tile of THIS sub-tile ([key][q], 8-byte chunks
+                # XOR-swizzled by the key; the address register carries the (sp, jp, lane) part, the key block is an immediate)
+                b = DSF + 4 * (2 * kb + sp) + 2 * jp
+                tasks.append(Task(f"ds_write_b64 v{DSWR + 2 * sp + jp}, v[{b}:{b + 1}] offset:@DSW+{kb * 32 * 64}", COST["ldsw"], rel_ds,
+                                  gD + 8, "ldsw", ("dsw", kb, sp, jp), after=cv))
+    for g4 in range(4):
+        d0 = SACC + 4 * g4
+        t = Task(f"ds_read_b128 v[{d0}:{d0 + 3}], %[rc] offset:@RC+{32 * g4}", COST["lds"], -READ_AHEAD - 4, -READ_LATEST, "lds",
+                 ("RCS",) if g4 == 3 else ("rcs", g4))
+        t.release = max(t.release, max(last_p[0].deadline, last_p[1].deadline) - NS + 1)
+        t.deadline = max(t.deadline, t.release)
+        tasks.append(t)
+    for g4 in range(4):
+        d0 = DPACC + 4 * g4
+        t = Task(f"ds_read_b128 v[{d0}:{d0 + 3}], %[rc] offset:@RC+{128 + 32 * g4}", COST["lds"], gB - READ_AHEAD - 4, gB - READ_LATEST, "lds",
+                 ("RCD",) if g4 == 3 else ("rcd", g4))
+        t.release = max(t.release, max(last_d[0].deadline, last_d[1].deadline) - NS + 1)
+        t.deadline = max(t.deadline, t.release)
+        tasks.append(t)
+    if chain:
+        # The chained kernel keeps the running dQ sums in a layout of its own -- [tile][wave][g][lane] x 4 floats, register
+        # 4 g + e of the tile = float e of the lane's 16 bytes -- so a tile moves with four 1-KiB instructions each way.
+        # Stores of the tile E has just finished go in front of the barrier (whose vmcnt(0) then says they are out: the
+        # kernel publishes its progress right after the body); the loads of the next tile's running sum follow the barrier
+        # and have until the next body's E stage.  Out-of-range soffsets / a null descriptor make either a no-op (zeros).
+        st = [Task(f"buffer_store_dwordx4 v[{DQT + 4 * g}:{DQT + 4 * g + 3}], %[dqv], %[drs], %[dso] offen offset:{1024 * g}", COST["vmem"],
+                   gE + 16 + 3, gE + 16 + 8, "vmem", ("dqst", g)) for g in range(4)]
+        tasks.extend(st)
+        for g in range(4):
+            tasks.append(Task(f"buffer_load_dwordx4 v[{DQT + 4 * g}:{DQT + 4 * g + 3}], %[dqv], %[lrs], %[lso] offen offset:{1024 * g}@LDSC",
+                              COST["vmem"], gD + 9, NS - 1, "vmem", ("dqld", g), after=st))
+    return mfma, tasks, NS
+
+
+def render_lines(mfma, per_gap, NS):
+    """base.render_lines, with LDS writes counted in the issue order too (they share lgkmcnt and return in order)."""
+    for g in per_gap:
+        for t in per_gap[g]:
+            if t.kind == "ldsw":
+                t.kind = "lds"
+    return base.render_lines(mfma, per_gap, NS)
+
+
+def resolve(lines, buf, par):
+    """Body of the sub-tile in ring buffer `buf` whose dS tile is `par`; E reads the previous sub-tile's dS tile (par ^ 1)."""
+    def bases(b):
+        return {"Q": b * BUFB, "G": b * BUFB + 32 * ROWB, "RC": b * BUFB}
+    cur, nxt = bases(buf), bases((buf + 1) % 3)
+    out, barrier_done, e_wait = [], False, False
+    for l in lines:
+        b = cur
+        is_next = l.startswith("@N ")
+        if is_next:
+            l, b = l[3:], nxt
+            if not barrier_done and l.startswith("ds_read"):
+                out.append("s_waitcnt vmcnt(0)")
+                out.append("s_barrier")
+                barrier_done = True
+        if not e_wait and l.startswith("v_mfma") and l.split()[1].startswith(f"v[{DQT}:"):
+            out.append("s_waitcnt vmcnt(%c[vm])")      # the running dQ sum the kernel loaded into DQT ahead of this body has landed
+            e_wait = True
+        if "ds_write" in l:
+            assert not barrier_done, "a dS write behind the barrier that publishes the dS tile"
+        if "buffer_store" in l:
+            assert not barrier_done, "a dQ store behind the barrier whose vmcnt(0) the kernel's progress flag relies on"
+        if "buffer_load" in l:
+            assert barrier_done and not is_next, "a dQ load in front of the barrier (its vmcnt(0) would wait for it)"
+        # E reads of the NEXT body (wrapped) read the tile this body wrote (par); in-body E reads the previous one
+        l = re.sub(r"@DSP\+(\d+)", lambda m: str((par if is_next else par ^ 1) * DSTILE + int(m.group(1))), l)
+        # sc1: past the CU's vector cache (a workgroup may meet the same running-sum lines twice when a head has more key
+        # blocks than the XCD has CUs); the XCD's L2 serves them
+        l = l.replace("@LDSC", os.environ.get("FA2_GEN_LDSC", " sc1"))
+        l = re.sub(r"@DSW\+(\d+)", lambda m: str(par * DSTILE + int(m.group(1))), l)
+        l = re.sub(r"@(Q|G|RC)\+(\d+)", lambda m: str(b[m.group(1)] + int(m.group(2))), l)
+        out.append(l)
+    assert barrier_done
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--check", action="store_true")
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "cuda_flashattention_amd", "csrc",
+                                                  "fa2_bwd_fused_body.inc"))
+    args = ap.parse_args()
+    mfma, tasks, NS = build()
+    per_gap, load = base.place(tasks, NS)
+    lines, pro = render_lines(mfma, per_gap, NS)
+    cm, ct, _ = build(chain=True)
+    cper_gap, cload = base.place(ct, NS)
+    clines, cpro = render_lines(cm, cper_gap, NS)
+    assert cpro == pro
+    if args.check:
+        print("   chained load:", " ".join(str(l) for l in cload))
+        print(f"fused D=128: {len(lines)} lines, {sum('v_mfma' in l for l in lines)} MFMAs, {len(pro)} early, max gap load {max(load)}, "
+              f"{sum(l > base.GAP_BUDGET for l in load)} of {NS} gaps over {base.GAP_BUDGET}")
+        print("   load:", " ".join(str(l) for l in load))
+        return
+    chunks = ["// GENERATED by tools/gen_fused_body.py -- do not edit.  Main-loop bodies of the fused five-product backward prototype:\n"
+              "// FA2_FUSED_BODY_B<ring buffer>_P<dS tile parity>, prologue FA2_FUSED_PRO.  Register and LDS maps: the generator.\n",
+              f"#define FA2_FUSED_VF {VF}\n#define FA2_FUSED_DQT {DQT}\n#define FA2_FUSED_ROFFK {ROFFK}\n#define FA2_FUSED_DSWR {DSWR}\n"
+              f"#define FA2_FUSED_DSRD {DSRD}\n#define FA2_FUSED_KT {KT}\n#define FA2_FUSED_QRING {QRING}\n#define FA2_FUSED_BUFB {BUFB}\n"
+              f"#define FA2_FUSED_DSB {DSB}\n#define FA2_FUSED_DSTILE {DSTILE}\n#define FA2_FUSED_LDS {LDS_BYTES}\n"]
+    p = [l for l in resolve(pro, 2, 1) if l not in ("s_waitcnt vmcnt(0)", "s_barrier")]      # 'next' of (buffer 2, parity 1) = (0, 0)
+    p.append("s_waitcnt lgkmcnt(0)")
+    chunks.append("#define FA2_FUSED_PRO \\\n" + base.c_string(p) + "\n")
+    for buf in range(3):
+        for par in range(2):
+            chunks.append(f"#define FA2_FUSED_BODY_B{buf}_P{par} \\\n" + base.c_string(resolve(lines, buf, par)) + "\n")
+            chunks.append(f"#define FA2_FUSED_CBODY_B{buf}_P{par} \\\n" + base.c_string(resolve(clines, buf, par)) + "\n")
+    with open(args.out, "w") as f:
+        f.write("\n".join(chunks))
+    print("wrote", args.out)
+
+
+if __name__ == "__main__":
+    main()
