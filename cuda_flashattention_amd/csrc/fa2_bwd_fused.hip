@@ -43,15 +43,25 @@ __device__ __forceinline__ void fused_vset(uint32_t x)
     [r6] "v"(roff[6]), [r7] "v"(roff[7]), [t0] "v"(toff[0]), [t1] "v"(toff[1]), [t2] "v"(toff[2]), [t3] "v"(toff[3]), [t4] "v"(toff[4]),   \
     [t5] "v"(toff[5]), [t6] "v"(toff[6]), [t7] "v"(toff[7]), [rc] "v"(rcv), [c2] "s"(c2)
 
-// chained kernel: the body stores the dQ tile it has just finished (drs, dso) and loads the next running sum (lrs, lso)
+// chained kernel: everything a step does is inside the body (tools/gen_fused_body.py lists the operands)
+struct FusedStep {
+    __amdgpu_buffer_rsrc_t drs, lrs, qrs, grs, rcrs, ctl;
+    uint32_t dso, lso, qso, rcso, pvo, mso;
+    int need, pval;
+};
 template <int BUF, int PAR, int VMW>
 __device__ __forceinline__ void fused_cbody(const uint32_t (&roff)[8], const uint32_t (&toff)[8], uint32_t rcv, float c2, uint32_t dqv,
-                                            __amdgpu_buffer_rsrc_t drs, uint32_t dso, __amdgpu_buffer_rsrc_t lrs, uint32_t lso)
+                                            uint32_t dvo, uint32_t rcvo, uint32_t mw, uint32_t mw2, int wv, const FusedStep& f, int& err)
 {
-#define FA2_FUSED_CASE(B, P)                                                                                                     \
-    if constexpr (BUF == B && PAR == P)                                                                                          \
-        asm volatile(FA2_FUSED_CBODY_B##B##_P##P : : FA2_FUSED_OPS, [vm] "i"(VMW), [dqv] "v"(dqv), [drs] "s"(drs), [dso] "s"(dso), \
-                     [lrs] "s"(lrs), [lso] "s"(lso) : FA2_FUSED_CLOBBERS);
+#define FA2_FUSED_CASE(B, P)                                                                                                          \
+    if constexpr (BUF == B && PAR == P)                                                                                               \
+        asm volatile(FA2_FUSED_CBODY_B##B##_P##P                                                                                      \
+                     : [err] "+s"(err)                                                                                                \
+                     : FA2_FUSED_OPS, [vm] "i"(VMW), [dqv] "v"(dqv), [drs] "s"(f.drs), [dso] "s"(f.dso), [lrs] "s"(f.lrs), [lso] "s"(f.lso), \
+                       [mw] "s"(mw), [mw2] "s"(mw2), [qrs] "s"(f.qrs), [grs] "s"(f.grs), [rcrs] "s"(f.rcrs), [qso] "s"(f.qso),           \
+                       [rcso] "s"(f.rcso), [dvo] "v"(dvo), [rcvo] "v"(rcvo), [wv] "s"(wv), [ctl] "s"(f.ctl), [pvo] "s"(f.pvo),           \
+                       [mso] "s"(f.mso), [need] "s"(f.need), [pval] "s"(f.pval)                                                        \
+                     : FA2_FUSED_CLOBBERS, "s12", "s13", "scc", "exec", "m0", "v39");
     FA2_FUSED_CASE(0, 0) FA2_FUSED_CASE(0, 1) FA2_FUSED_CASE(1, 0) FA2_FUSED_CASE(1, 1) FA2_FUSED_CASE(2, 0) FA2_FUSED_CASE(2, 1)
 #undef FA2_FUSED_CASE
 }
@@ -127,19 +137,7 @@ __device__ __forceinline__ int fused_load_sc1(const int* p)
     return v;
 }
 // The progress of the previous key block is prefetched into v39, a register the compiler does not allocate (the kernel is
-// limited to v0..v38): were it a compiler-managed value, the compiler would wait for ALL vector memory traffic before reading
-// it -- including the running-sum loads the body has just issued.  The load is issued in front of a body, whose vmcnt(0)
-// completes it; it is read after the body.
-__device__ __forceinline__ void fused_seen_issue(__amdgpu_buffer_rsrc_t rs, uint32_t off)
-{
-    asm volatile("buffer_load_dword v39, off, %0, %1 sc1" : : "s"(rs), "s"(off) : "memory", "v39");
-}
-__device__ __forceinline__ int fused_seen_read()
-{
-    int v;
-    asm volatile("v_readfirstlane_b32 %0, v39" : "=s"(v) : : "v39");
-    return v;
-}
+// limited to v0..v38) and the generated body owns: issued at the top of a body, read behind its barrier.
 __device__ __forceinline__ void fused_seen_set(int v)
 {
     asm volatile("v_mov_b32 v39, %0" : : "s"(v) : "v39");
@@ -322,6 +320,8 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
         const int prev_off = (int)((prev - fp.ctl) * 4);
         int* const mine = prog_base + head * ncb + cb;
         if constexpr (CHAIN) fused_seen_set(0);          // what prev was last seen at
+        int err = 0;                                     // raised by a body whose wait for the previous key block ran out
+        if constexpr (CHAIN) err = __builtin_amdgcn_readfirstlane(fused_load_sc1(fp.ctl + kCtlError));   // someone else's did: do not wait
 #ifdef FA2_FUSED_STATS
         int st_steps = 0, st_polls = 0, st_cycles = 0;
         const uint64_t u0 = __builtin_readcyclecounter();
@@ -331,30 +331,29 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
         auto step = [&](auto BUF, auto PAR, int t) {
             constexpr int buf = decltype(BUF)::value, par = decltype(PAR)::value;
             if constexpr (CHAIN) {
-                // body t: E forms the dQ tile of sub-tile t - 1 on top of the running sum loaded by body t - 1, stores it, and
-                // loads the running sum of sub-tile t, which key block cb - 1 must have stored by now
-                if (cb > 0 && t < ntiles) {
-                    int spins = 0;
-#ifdef FA2_FUSED_STATS
-                    const uint64_t w0 = __builtin_readcyclecounter();
-#endif
-                    if (!(FA2_FUSED_DIAG & 1) && fused_seen_read() < t + 1)
-                        while (fused_load_sc1(prev) < t + 1)
-                            if (fused_spin_over(fp.ctl, ++spins)) break;
-#ifdef FA2_FUSED_STATS
-                    if (spins) { st_steps++; st_polls += spins; st_cycles += (int)(__builtin_readcyclecounter() - w0); }
-#endif
-                }
-                stage(t + 1, (buf + 1) % 3);             // rows past the end read as zeros
-                // how far prev is, for the next step.  Asynchronous; the wait in front of the E chain (all but the VMW youngest
-                // operations: >= 4 DMA pieces and this load) covers the running-sum loads without waiting for this one.
-                fused_seen_issue(ctl_rsrc, (uint32_t)prev_off);      // always: VMW counts it (cb == 0 reads its own slot - 1: unused)
+                // body t: DMA of sub-tile t + 1; E forms the dQ tile of sub-tile t - 1 on top of the running sum loaded by body
+                // t - 1 and stores it; behind the barrier it publishes "t sub-tiles out", waits until key block cb - 1 has
+                // published t + 1, and loads the running sum of sub-tile t
+                FusedStep f;
                 const bool live = t >= 1 && t <= ntiles;
-                const uint32_t dso = (uint32_t)__builtin_amdgcn_readfirstlane((t - 1) * TROWS * D * 4);
-                fused_cbody<buf, par, VMW>(roff, toff, rcv, c2, dqv, live ? dq_rsrc : null_rsrc, dso, cb > 0 && !(FA2_FUSED_DIAG & 2) ? dq_rsrc : null_rsrc,
-                                           dso + TROWS * D * 4);
-                // the body's barrier sits behind a vmcnt(0) that covers every wave's stores: sub-tiles < t are out
-                if (live && tid == 0) fused_store_flag(mine, t);
+                f.drs = live ? dq_rsrc : null_rsrc;
+                f.lrs = cb > 0 && !(FA2_FUSED_DIAG & 2) ? dq_rsrc : null_rsrc;
+                f.dso = (uint32_t)__builtin_amdgcn_readfirstlane((t - 1) * TROWS * D * 4);
+                f.lso = f.dso + TROWS * D * 4;
+                f.qrs = q_rsrc; f.grs = g_rsrc; f.rcrs = rc_rsrc; f.ctl = ctl_rsrc;
+                f.qso = (uint32_t)((t + 1) * TROWS * ROWB + wave * 1024);
+                f.rcso = (uint32_t)((t + 1) * TROWS * 4);
+                f.pvo = (uint32_t)prev_off; f.mso = (uint32_t)prev_off + 4;
+                f.need = (cb > 0 && t < ntiles && !err && !(FA2_FUSED_DIAG & 1)) ? t + 1 : (int)0x80000000;
+                f.pval = t < ntiles ? t : ntiles;
+#ifdef FA2_FUSED_STATS2
+                const uint64_t b0 = __builtin_readcyclecounter();
+#endif
+                fused_cbody<buf, par, VMW>(roff, toff, rcv, c2, dqv, (uint32_t)doff, (uint32_t)rcoff, lbase + QRING + wave * 1024,
+                                           lbase + QRING + wave * 128, wave, f, err);
+#ifdef FA2_FUSED_STATS2
+                st_cycles += (int)(__builtin_readcyclecounter() - b0);       // cycles inside the bodies (reported as "waited")
+#endif
             } else {
                 stage(t + 1, (buf + 1) % 3);
                 fused_body<buf, par, VMW>(roff, toff, rcv, c2);
@@ -374,6 +373,8 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
             step(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, t + 5);
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if constexpr (CHAIN)
+            if (err && tid == 0) atomicExch(fp.ctl + kCtlError, 1);
 
         mfma_acc_settle();
         // lane indices recomputed here so that nothing per-lane has to live (or spill) across the loop

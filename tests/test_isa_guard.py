@@ -126,8 +126,8 @@ def test_named_vgprs_are_the_bodies_own(asm, pattern, limit, top128, top64):
 
 
 def test_fused_backward_kernel(asm):
-    """The single-kernel backward is compiled with amdgpu_num_vgpr(39): v39 is the kernel's own prefetch register, v40..v255
-    belong to the generated body (tools/gen_fused_body.py).  Its hot loop holds six bodies of 80 MFMAs (ring of three Q/dO
+    """The single-kernel backward is compiled with amdgpu_num_vgpr(39): v39 (progress-word prefetch) and v40..v255 belong to
+    the generated body (tools/gen_fused_body.py).  Its hot loop holds six bodies of 80 MFMAs (ring of three Q/dO
     buffers x two dS tiles), the chained form's bodies carry their four dQ stores in front of the barrier and the four
     running-sum loads behind it, and nothing in the loop touches scratch."""
     ks = {n: k for n, k in _kernels(asm["fa2_bwd_fused"]).items() if "fa2_bwd_fused_kernelILb" in n}
@@ -148,14 +148,21 @@ def test_fused_backward_kernel(asm):
         assert len(bodies) == 6
         for b in bodies:
             st = [i for i, s in enumerate(b) if s.startswith("buffer_store_dwordx4")]
-            ld = [i for i, s in enumerate(b) if s.startswith("buffer_load_dwordx4")]
+            ld = [i for i, s in enumerate(b) if s.startswith("buffer_load_dwordx4 v[")]          # running sums (not the LDS-DMA)
+            dma = [i for i, s in enumerate(b) if s.startswith("buffer_load_dword") and s.endswith(" lds")]
             bar = [i for i, s in enumerate(b) if s.startswith("s_barrier")]
             assert len(bar) == 1 and b[bar[0] - 1].startswith("s_waitcnt vmcnt(0)")
             if chain:
                 assert len(st) == 4 and len(ld) == 4 and max(st) < bar[0] < min(ld), name
                 assert all(" sc1" in b[i] for i in ld)
+                # the step's LDS-DMA, progress prefetch and hand-shake are inside the body: 4 + 1 DMA issues in front of the
+                # barrier, the publishing store and the bounded poll loop behind it, in front of the running-sum loads
+                assert len(dma) == 5 and max(dma) < bar[0]
+                pub = [i for i, s in enumerate(b) if s.startswith("buffer_store_dword v39")]
+                assert len(pub) == 1 and bar[0] < pub[0] < min(ld)
+                assert sum(s.startswith("s_cbranch_scc1 1b") for s in b) == 1
             else:
-                assert not st and not ld
+                assert not st and not ld and not dma
 
 
 def test_forward_loop_shape(asm):

@@ -22,7 +22,9 @@ Registers (kernel compiled with amdgpu_num_vgpr(40)): a[0:128) dK^T, a[128:256) 
     handed over by the previous key block's workgroup); ROFFK (8: row-read addresses of the wave's K rows), DSWR (4: dS
     write addresses), DSRD (2), KT (2).
 Two families: FA2_FUSED_BODY_* (the dQ tile is left in DQT for the kernel) and FA2_FUSED_CBODY_* (chained kernel: the body
-itself stores the finished tile and loads the next running sum; extra operands %[dqv], %[drs], %[dso], %[lrs], %[lso]).
+itself stores the finished tile, loads the next running sum, issues the next tile's LDS-DMA, and does the hand-shake with
+the neighbouring key blocks; extra operands %[dqv], %[drs], %[dso], %[lrs], %[lso] (dQ tiles), %[mw], %[mw2], %[qrs], %[grs],
+%[rcrs], %[qso], %[rcso], %[dvo], %[rcvo], %[wv] (DMA), %[ctl], %[pvo], %[mso], %[need], %[pval], %[err] (progress words)).
 Operands: %[r*], %[t*] (Q/dO ring addresses), %[rc], %[c2], %[vm] (immediate: how many of the kernel's vector-memory
 operations may still be in flight when the E chain starts -- those issued after its loads into DQT; 63 = no such loads).
 Same generator core as tools/gen_dkdv_body.py (cyclic bodies, counted waits derived from the issue order)."""
@@ -222,6 +224,20 @@ def build(chain=False):
         # Stores of the tile E has just finished go in front of the barrier (whose vmcnt(0) then says they are out: the
         # kernel publishes its progress right after the body); the loads of the next tile's running sum follow the barrier
         # and have until the next body's E stage.  Out-of-range soffsets / a null descriptor make either a no-op (zeros).
+        # What the kernel would otherwise do between two bodies, with the matrix pipe idle, is part of the body too: the
+        # LDS-DMA of the next Q / dO tile (two 1-KiB pieces of each per wave; waves 0 and 1 also fetch the 32 + 32 row
+        # constants) and the prefetch of the previous key block's progress word into v39.
+        for which in (0, 1):
+            for i in (0, 1):
+                rs = "%[grs]" if which else "%[qrs]"
+                mid = f"s_add_u32 s12, %[qso], {4096 * i}" if i else "s_nop 0"
+                tasks.append(Task(f"s_add_u32 m0, %[mw], @NB+{8192 * which + 4096 * i}\n\t{mid}\n\t"
+                                  f"buffer_load_dwordx4 %[dvo], {rs}, {'s12' if i else '%[qso]'} offen lds", COST["vmem"] + 2, 1, 12, "vmem",
+                                  ("dma", which, i)))
+        tasks.append(Task(f"s_cmp_lt_u32 %[wv], 2\n\ts_cbranch_scc0 4f\n\ts_mov_b64 exec, 0xffffffff\n\ts_add_u32 m0, %[mw2], @NB+{2 * 32 * ROWB}\n\t"
+                          "s_nop 0\n\tbuffer_load_dword %[rcvo], %[rcrs], %[rcso] offen lds\n\ts_mov_b64 exec, -1\n\t4:", COST["vmem"] + 6, 1, 12,
+                          "vmem", ("dma", "rc")))
+        tasks.append(Task("buffer_load_dword v39, off, %[ctl], %[pvo] sc1", COST["vmem"], 1, 12, "vmem", ("seen",)))
         st = [Task(f"buffer_store_dwordx4 v[{DQT + 4 * g}:{DQT + 4 * g + 3}], %[dqv], %[drs], %[dso] offen offset:{1024 * g}", COST["vmem"],
                    gE + 16 + 3, gE + 16 + 8, "vmem", ("dqst", g)) for g in range(4)]
         tasks.extend(st)
@@ -240,8 +256,38 @@ def render_lines(mfma, per_gap, NS):
     return base.render_lines(mfma, per_gap, NS)
 
 
-def resolve(lines, buf, par):
+SPIN_LIMIT = 1 << 22
+
+# Behind the barrier of a chained body (every wave's dQ stores are out): publish this key block's progress -- each wave's
+# lane 0 writes the same word -- and make sure the previous key block has stored the running sum the loads that follow
+# will fetch.  v39 holds the progress word prefetched at the top of the body; a wait that runs out (SPIN_LIMIT polls)
+# raises %[err] and goes on, so that a fault ends in poisoned output, not in a hung GPU.
+AFTER_BARRIER = [
+    "v_readfirstlane_b32 s12, v39",
+    "v_mov_b32 v39, %[pval]",
+    "s_mov_b64 exec, 1",
+    "buffer_store_dword v39, off, %[ctl], %[mso]",
+    "s_mov_b64 exec, -1",
+    "s_cmp_ge_i32 s12, %[need]",
+    "s_cbranch_scc1 2f",
+    f"s_mov_b32 s13, {SPIN_LIMIT}",
+    "1:",
+    "buffer_load_dword v39, off, %[ctl], %[pvo] sc1",
+    "s_waitcnt vmcnt(0)",
+    "v_readfirstlane_b32 s12, v39",
+    "s_cmp_ge_i32 s12, %[need]",
+    "s_cbranch_scc1 2f",
+    "s_sub_u32 s13, s13, 1",
+    "s_cmp_lg_u32 s13, 0",
+    "s_cbranch_scc1 1b",
+    "s_mov_b32 %[err], 1",
+    "2:",
+]
+
+
+def resolve(lines, buf, par, chain=False):
     """Body of the sub-tile in ring buffer `buf` whose dS tile is `par`; E reads the previous sub-tile's dS tile (par ^ 1)."""
+    lines = [part for l in lines for part in (l.split("\n\t") if not l.startswith("@N ") else [l])]
     def bases(b):
         return {"Q": b * BUFB, "G": b * BUFB + 32 * ROWB, "RC": b * BUFB}
     cur, nxt = bases(buf), bases((buf + 1) % 3)
@@ -252,8 +298,13 @@ def resolve(lines, buf, par):
         if is_next:
             l, b = l[3:], nxt
             if not barrier_done and l.startswith("ds_read"):
+                # the next tile's DMA (issued in front of this body) has landed, and the chained body's dQ stores are out.
+                # (Letting the stores stay in flight here -- vmcnt(4) -- and publishing one body later was measured: no
+                # faster per step, and a longer start-up skew along the chain.)
                 out.append("s_waitcnt vmcnt(0)")
                 out.append("s_barrier")
+                if chain:
+                    out.extend(AFTER_BARRIER)
                 barrier_done = True
         if not e_wait and l.startswith("v_mfma") and l.split()[1].startswith(f"v[{DQT}:"):
             out.append("s_waitcnt vmcnt(%c[vm])")      # the running dQ sum the kernel loaded into DQT ahead of this body has landed
@@ -262,8 +313,9 @@ def resolve(lines, buf, par):
             assert not barrier_done, "a dS write behind the barrier that publishes the dS tile"
         if "buffer_store" in l:
             assert not barrier_done, "a dQ store behind the barrier whose vmcnt(0) the kernel's progress flag relies on"
-        if "buffer_load" in l:
+        if "buffer_load_dwordx4 v[" in l:
             assert barrier_done and not is_next, "a dQ load in front of the barrier (its vmcnt(0) would wait for it)"
+        l = re.sub(r"@NB\+(\d+)", lambda m: str(((buf + 1) % 3) * BUFB + int(m.group(1))), l)
         # E reads of the NEXT body (wrapped) read the tile this body wrote (par); in-body E reads the previous one
         l = re.sub(r"@DSP\+(\d+)", lambda m: str((par if is_next else par ^ 1) * DSTILE + int(m.group(1))), l)
         # sc1: past the CU's vector cache (a workgroup may meet the same running-sum lines twice when a head has more key
@@ -300,13 +352,13 @@ def main():
               f"#define FA2_FUSED_VF {VF}\n#define FA2_FUSED_DQT {DQT}\n#define FA2_FUSED_ROFFK {ROFFK}\n#define FA2_FUSED_DSWR {DSWR}\n"
               f"#define FA2_FUSED_DSRD {DSRD}\n#define FA2_FUSED_KT {KT}\n#define FA2_FUSED_QRING {QRING}\n#define FA2_FUSED_BUFB {BUFB}\n"
               f"#define FA2_FUSED_DSB {DSB}\n#define FA2_FUSED_DSTILE {DSTILE}\n#define FA2_FUSED_LDS {LDS_BYTES}\n"]
-    p = [l for l in resolve(pro, 2, 1) if l not in ("s_waitcnt vmcnt(0)", "s_barrier")]      # 'next' of (buffer 2, parity 1) = (0, 0)
+    p = [l for l in resolve(pro, 2, 1) if not l.startswith("s_waitcnt vmcnt") and l != "s_barrier"]      # 'next' of (buffer 2, parity 1) = (0, 0)
     p.append("s_waitcnt lgkmcnt(0)")
     chunks.append("#define FA2_FUSED_PRO \\\n" + base.c_string(p) + "\n")
     for buf in range(3):
         for par in range(2):
             chunks.append(f"#define FA2_FUSED_BODY_B{buf}_P{par} \\\n" + base.c_string(resolve(lines, buf, par)) + "\n")
-            chunks.append(f"#define FA2_FUSED_CBODY_B{buf}_P{par} \\\n" + base.c_string(resolve(clines, buf, par)) + "\n")
+            chunks.append(f"#define FA2_FUSED_CBODY_B{buf}_P{par} \\\n" + base.c_string(resolve(clines, buf, par, chain=True)) + "\n")
     with open(args.out, "w") as f:
         f.write("\n".join(chunks))
     print("wrote", args.out)

@@ -51,7 +51,9 @@ if __name__ == "__main__":
     Q, K, V, dO = mk(), mk(), mk(), mk()
     scale = d ** -0.5
     O, L = fa.flash_attention_2_forward(Q, K, V)
-    ref = fa.flash_attention_2_backward(Q, K, V, O, L, dO, scale)
+    ref = [torch.empty_like(Q) for _ in range(3)]
+    ws0 = torch.empty(lib.fa2_backward_workspace_bytes(B, H, N, d, 0), dtype=torch.uint8, device="cuda")
+    for ph in (1, 6): fa.flash_attention_2_backward(Q, K, V, O, L, dO, scale, dQ=ref[0], dK=ref[1], dV=ref[2], workspace=ws0, phases=ph)
     nb = lib.fa2_backward_fused_workspace_bytes(B, H, N, d)
     ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
     got = fused(Q, K, V, O, L, dO, scale, ws)

@@ -12,7 +12,8 @@ O, L = fa.flash_attention_2_forward(Q, K, V)
 ws = torch.empty(lib.fa2_backward_fused_workspace_bytes(B, H, N, d), dtype=torch.uint8, device="cuda")
 ws2 = torch.empty(lib.fa2_backward_workspace_bytes(B, H, N, d, 0), dtype=torch.uint8, device="cuda")
 dQ, dK, dV = torch.empty_like(Q), torch.empty_like(Q), torch.empty_like(Q)
-two = lambda: fa.flash_attention_2_backward(Q, K, V, O, L, dO, dQ=dQ, dK=dK, dV=dV, workspace=ws2)
+def two():
+    for ph in (1, 6): fa.flash_attention_2_backward(Q, K, V, O, L, dO, dQ=dQ, dK=dK, dV=dV, workspace=ws2, phases=ph)
 fus = lambda: fused(Q, K, V, O, L, dO, d**-0.5, ws, MODE)
 def block(f, n=10):
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
