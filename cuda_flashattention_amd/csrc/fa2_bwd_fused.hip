@@ -236,8 +236,11 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
     const auto ctl_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)fp.ctl, 0, CHAIN ? fused_ctl_ints(p.BH, ncb) * 4 : 0, 0x00020000);
 
     for (;;) {
+#ifdef FA2_FUSED_STATS
+        const uint64_t s_pull = __builtin_readcyclecounter();
+#endif
         // ---- the unit: (head, key block)
-        int head, cb;
+        int head, cb, err0 = 0;
         if constexpr (CHAIN) {
             if (tid == 0) {
                 int hd = -1, j = 0;
@@ -260,10 +263,12 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
                 }
                 mail[0] = hd;
                 mail[1] = j;
+                mail[2] = hd >= 0 ? fused_load_sc1(fp.ctl + kCtlError) : 0;     // somebody's wait ran out: nobody waits any more
             }
             __syncthreads();
             head = __builtin_amdgcn_readfirstlane(mail[0]);
             cb = __builtin_amdgcn_readfirstlane(mail[1]);
+            err0 = __builtin_amdgcn_readfirstlane(mail[2]);
             if (head < 0) break;
         } else {
             map_block(blockIdx.x, p.BH, ncb, head, cb);
@@ -320,8 +325,7 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
         const int prev_off = (int)((prev - fp.ctl) * 4);
         int* const mine = prog_base + head * ncb + cb;
         if constexpr (CHAIN) fused_seen_set(0);          // what prev was last seen at
-        int err = 0;                                     // raised by a body whose wait for the previous key block ran out
-        if constexpr (CHAIN) err = __builtin_amdgcn_readfirstlane(fused_load_sc1(fp.ctl + kCtlError));   // someone else's did: do not wait
+        int err = err0;                                  // raised by a body whose wait for the previous key block ran out
 #ifdef FA2_FUSED_STATS
         int st_steps = 0, st_polls = 0, st_cycles = 0;
         const uint64_t u0 = __builtin_readcyclecounter();
@@ -374,7 +378,10 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         if constexpr (CHAIN)
-            if (err && tid == 0) atomicExch(fp.ctl + kCtlError, 1);
+            if (err && !err0 && tid == 0) atomicExch(fp.ctl + kCtlError, 1);
+#ifdef FA2_FUSED_STATS
+        const uint64_t s_loop = __builtin_readcyclecounter();
+#endif
 
         mfma_acc_settle();
         // lane indices recomputed here so that nothing per-lane has to live (or spill) across the loop
@@ -404,7 +411,7 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
             atomicAdd((unsigned long long*)(fp.ctl + kCtlError + 4), (unsigned long long)st_cycles);
             atomicAdd((unsigned long long*)(fp.ctl + kCtlError + 6), (unsigned long long)(__builtin_readcyclecounter() - u0));
             int* rec = prog_base + p.BH * ncb + 8 * (head * ncb + cb);       // per unit: xcc, cycles waited, steps waited, start, end
-            rec[0] = xcc; rec[1] = st_cycles; rec[2] = st_steps;
+            rec[0] = xcc; rec[1] = st_cycles; rec[2] = (int)(u0 - s_pull); rec[3] = (int)(__builtin_readcyclecounter() - s_loop);
             *(unsigned long long*)(rec + 4) = u0; *(unsigned long long*)(rec + 6) = __builtin_readcyclecounter();
         }
 #endif

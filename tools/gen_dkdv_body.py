@@ -43,6 +43,7 @@ COST = {"lds": 4, "valu": 4, "exp": 8, "cvt": 4, "mask": 16}
 READ_AHEAD = 7           # issue a fragment read this many MFMAs before its consumer ...
 READ_LATEST = 4          # ... and not later than this many
 NSLOT = 7
+WAIT_LOOK = int(os.environ.get("FA2_GEN_WAIT_LOOK", "0"))       # see render_lines; 2 was MEASURED 2-3 % slower (fused backward)
 
 
 class Regs:
@@ -334,6 +335,17 @@ def render_lines(mfma, per_gap, NS):
             # a wait is needed only if it asks for something an earlier wait has not already covered (LDS returns in order)
             if cnt is not None and len(issued) - 1 - cnt <= waited_upto[0]:
                 cnt = None
+            if cnt is not None and WAIT_LOOK:
+                # experiment: fewer s_waitcnt (each is an issue slot) by letting one wait also cover what the next WAIT_LOOK
+                # MFMAs need, as far as it is in flight.  It halves the waits and is slower: the merged wait stalls on reads
+                # issued only two or three MFMAs earlier.  Off by default.
+                for g2 in range(g + 1, g + 1 + WAIT_LOOK):
+                    p2 = period + g2 // NS
+                    for k in mfma[g2 % NS][1]:
+                        hits = [i for i, (p, kk) in enumerate(issued) if kk == k and p == p2]
+                        if hits:
+                            pos = max(pos, hits[-1])
+                cnt = min(len(issued) - 1 - pos, 15)
             if cnt is not None:
                 waited_upto[0] = len(issued) - 1 - cnt
             if period == 1:

@@ -25,7 +25,8 @@ Two families: FA2_FUSED_BODY_* (the dQ tile is left in DQT for the kernel) and F
 itself stores the finished tile, loads the next running sum, issues the next tile's LDS-DMA, and does the hand-shake with
 the neighbouring key blocks; extra operands %[dqv], %[drs], %[dso], %[lrs], %[lso] (dQ tiles), %[mw], %[mw2], %[qrs], %[grs],
 %[rcrs], %[qso], %[rcso], %[dvo], %[rcvo], %[wv] (DMA), %[ctl], %[pvo], %[mso], %[need], %[pval], %[err] (progress words)).
-Operands: %[r*], %[t*] (Q/dO ring addresses), %[rc], %[c2], %[vm] (immediate: how many of the kernel's vector-memory
+Operands: %[r*], %[t*] (Q/dO ring addresses), %[rc], %[c2] (scale * log2 e; %[c2p], the same in both halves of an
+SGPR pair, with FA2_GEN_PK=1), %[vm] (immediate: how many of the kernel's vector-memory
 operations may still be in flight when the E chain starts -- those issued after its loads into DQT; 63 = no such loads).
 Same generator core as tools/gen_dkdv_body.py (cyclic bodies, counted waits derived from the issue order)."""
 import argparse
@@ -74,9 +75,21 @@ def dv(kb, dt): b = A_DV + 16 * (kb * DT + dt); return f"a[{b}:{b + 15}]"
 DQTILE = f"v[{DQT}:{DQT + 15}]"
 
 
+# packed multiplies (v_pk_mul_f32 for the two scalings of a register pair): MEASURED SLOWER -- 971K instead of 882K cycles per
+# unit at (4,16,8192,128); a v_pk_mul_f32 costs the issue port about as much as four plain multiplies.  Kept as a switch.
+PK = os.environ.get("FA2_GEN_PK", "0") == "1"
+
+
 def build(chain=False):
     NS = 80
-    gA1, gB, gE, gC, gD = KS + 1, 16, 32, 48, 64
+    gA1, gB, gC, gD = KS + 1, 16, 48, 64
+    # B (dP', one dO fragment per pair of MFMAs: light on the LDS) and E (four transposed reads per MFMA: with all four
+    # waves in it at once, exactly what the LDS array can deliver) share gaps 16..47: the first four B pairs, then four
+    # groups of [B pair, four E steps] -- 75 % of the array instead of 25 % followed by 100 %.
+    ILV = os.environ.get("FA2_GEN_ILV", "1") == "1"
+    def gBp(sidx): return (gB + 2 * sidx) if (not ILV or sidx < 4) else (24 + 6 * (sidx - 4))
+    def gEs(sidx): return (32 + sidx) if not ILV else (24 + 6 * (sidx // 4) + 2 + sidx % 4)
+    gEend = gEs(15) + 1
     mfma = [None] * NS
     tasks = []
     ctr = [0]
@@ -114,23 +127,23 @@ def build(chain=False):
                     rd(f"ds_read_b128 {slot(b)}, v{ROFFK + s} offset:{kb * 32 * ROWB}", ("K", kb, s), g, fb)
                     mfma[g] = (f"v_mfma_f32_32x32x16_bf16 {sacc(kb)}, {slot(a)}, {slot(b)}, {sacc(kb)}", [("Q", kb, s), ("K", kb, s)])
         # ---- B: dP' (dO fragment shared by the two key blocks; V fragments are resident)
-        for s in range(KS):
-            g = gB + 2 * s
-            sg, fg = take(g + 1)
-            if rec:
-                rd(f"ds_read_b128 {slot(sg)}, %[r{s}] offset:@G+0", ("G", s), g, fg)
-                if s == 0:
-                    mfma[g] = (f"v_mfma_f32_32x32x16_bf16 {dpacc(1)}, {slot(sg)}, {vf(1, s)}, {dpacc(0)}", [("G", s), ("RCD",)])
-                    mfma[g + 1] = (f"v_mfma_f32_32x32x16_bf16 {dpacc(0)}, {slot(sg)}, {vf(0, s)}, {dpacc(0)}", [("G", s)])
-                else:
-                    mfma[g] = (f"v_mfma_f32_32x32x16_bf16 {dpacc(0)}, {slot(sg)}, {vf(0, s)}, {dpacc(0)}", [("G", s)])
-                    mfma[g + 1] = (f"v_mfma_f32_32x32x16_bf16 {dpacc(1)}, {slot(sg)}, {vf(1, s)}, {dpacc(1)}", [("G", s)])
         # ---- E: dQ of the previous sub-tile: 16 k-steps of 16 keys over the workgroup's 256 keys.  The K^T fragments go
         # through the regular slots; the dS fragments land in the four DSF tuples, which are idle from the previous body's D
         # stage to this body's dS packs (so E reads five MFMAs ahead instead of three).
+        # (fragment slots are handed out in the order of use: the two stages interleave)
         xbusy = [gD - NS + 6, gD - NS + 7, gD - NS + 14, gD - NS + 15]      # last D-stage readers of dsf(0,0), (1,0), (0,1), (1,1)
-        for s in range(16):
-            g = gE + s
+        for g, kind, s in sorted([(gBp(i), "B", i) for i in range(KS)] + [(gEs(i), "E", i) for i in range(16)]):
+            if kind == "B":
+                sg, fg = take(g + 1)
+                if rec:
+                    rd(f"ds_read_b128 {slot(sg)}, %[r{s}] offset:@G+0", ("G", s), g, fg)
+                    if s == 0:
+                        mfma[g] = (f"v_mfma_f32_32x32x16_bf16 {dpacc(1)}, {slot(sg)}, {vf(1, s)}, {dpacc(0)}", [("G", s), ("RCD",)])
+                        mfma[g + 1] = (f"v_mfma_f32_32x32x16_bf16 {dpacc(0)}, {slot(sg)}, {vf(0, s)}, {dpacc(0)}", [("G", s)])
+                    else:
+                        mfma[g] = (f"v_mfma_f32_32x32x16_bf16 {dpacc(0)}, {slot(sg)}, {vf(0, s)}, {dpacc(0)}", [("G", s)])
+                        mfma[g + 1] = (f"v_mfma_f32_32x32x16_bf16 {dpacc(1)}, {slot(sg)}, {vf(1, s)}, {dpacc(1)}", [("G", s)])
+                continue
             x = s % 4
             xr = DSF + 4 * x
             sb, fb = take(g)
@@ -177,26 +190,38 @@ def build(chain=False):
             use_pf = gC + 2 * sp * DT + kb
             for j in range(4):
                 pair = []
-                for r in (8 * sp + 2 * j, 8 * sp + 2 * j + 1):
-                    m = valu(f"v_mul_f32 {sreg(kb, r)}, %[c2], {sreg(kb, r)}", "valu", rel_exp, use_pf - 5)
+                r0 = 8 * sp + 2 * j
+                a0 = SACC + 16 * kb + r0
+                # both scalings of a register pair in one packed multiply (%[c2p]: c2 in both halves of an SGPR pair): the
+                # loop is bound by what one wave can ISSUE, and a packed fp32 multiply issues like a plain one
+                m2 = valu(f"v_pk_mul_f32 v[{a0}:{a0 + 1}], v[{a0}:{a0 + 1}], %[c2p]", "valu", rel_exp, use_pf - 5) if PK else None
+                for r in (r0, r0 + 1):
+                    m = m2 or valu(f"v_mul_f32 {sreg(kb, r)}, %[c2], {sreg(kb, r)}", "valu", rel_exp, use_pf - 5)
                     e = valu(f"v_exp_f32 {sreg(kb, r)}, {sreg(kb, r)}", "exp", rel_exp, use_pf - 4, after=[m])
                     exps[r] = e
                     pair.append(e)
                 valu(f"v_cvt_pk_bf16_f32 {pfw(kb, sp, j)}, {sreg(kb, 8 * sp + 2 * j)}, {sreg(kb, 8 * sp + 2 * j + 1)}", "cvt", rel_exp,
                      use_pf - 2, after=pair)
-        rel_ds = gB + 2 * (KS - 1) + kb + 3
+        rel_ds = gBp(KS - 1) + kb + 3
         for sp in (0, 1):
             use_ds = gD + 2 * sp * DT + kb
             for jp in (0, 1):
                 cv = []
                 for j in (2 * jp, 2 * jp + 1):
                     pair = []
-                    for r in (8 * sp + 2 * j, 8 * sp + 2 * j + 1):
+                    r0 = 8 * sp + 2 * j
+                    if PK:
+                        a0, d0 = SACC + 16 * kb + r0, DPACC + 16 * kb + r0
+                        t = valu(f"v_pk_mul_f32 v[{d0}:{d0 + 1}], v[{a0}:{a0 + 1}], v[{d0}:{d0 + 1}]", "valu", rel_ds, use_ds - 3,
+                                 after=[exps[r0], exps[r0 + 1]])
+                        pair.append(t)
+                        last_p[kb] = t
+                    for r in (() if PK else (r0, r0 + 1)):
                         t = valu(f"v_mul_f32 {dreg(kb, r)}, {sreg(kb, r)}, {dreg(kb, r)}", "valu", rel_ds, use_ds - 3, after=[exps[r]])
                         pair.append(t)
                         last_p[kb] = t
                     c = valu(f"v_cvt_pk_bf16_f32 {dsfw(kb, sp, j)}, {dreg(kb, 8 * sp + 2 * j)}, {dreg(kb, 8 * sp + 2 * j + 1)}", "cvt",
-                             max(rel_ds, gC), use_ds - 2, after=pair)       # the DSF tuples are E's dS fragment slots until E ends
+                             max(rel_ds, gEend), use_ds - 2, after=pair)    # the DSF tuples are E's dS fragment slots until E ends
                     cv.append(c)
                     last_d[kb] = c
                 # the packed pair (4 consecutive q of this lane's key) -> the dS tile of THIS sub-tile ([key][q], 8-byte chunks
@@ -239,7 +264,7 @@ def build(chain=False):
                           "vmem", ("dma", "rc")))
         tasks.append(Task("buffer_load_dword v39, off, %[ctl], %[pvo] sc1", COST["vmem"], 1, 12, "vmem", ("seen",)))
         st = [Task(f"buffer_store_dwordx4 v[{DQT + 4 * g}:{DQT + 4 * g + 3}], %[dqv], %[drs], %[dso] offen offset:{1024 * g}", COST["vmem"],
-                   gE + 16 + 3, gE + 16 + 8, "vmem", ("dqst", g)) for g in range(4)]
+                   gEend + 3, gEend + 8, "vmem", ("dqst", g)) for g in range(4)]
         tasks.extend(st)
         for g in range(4):
             tasks.append(Task(f"buffer_load_dwordx4 v[{DQT + 4 * g}:{DQT + 4 * g + 3}], %[dqv], %[lrs], %[lso] offen offset:{1024 * g}@LDSC",

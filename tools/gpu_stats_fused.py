@@ -32,3 +32,5 @@ for hd in np.argsort(t0[:, 0])[[0, 1, 8, 16, 63]]:
           f" | dur cb0 {int(dur[hd,0])} cb1 {int(dur[hd,1])} cb16 {int(dur[hd,16])} cb31 {int(dur[hd,-1])} | waited cb1 {rec[hd,1,1]} cb16 {rec[hd,16,1]} cb31 {rec[hd,-1,1]}")
 print("mean dur by cb:", " ".join(f"{int(x)}" for x in dur.mean(0)[::4]))
 print("mean waited by cb:", " ".join(f"{int(x)}" for x in rec[..., 1].mean(0)[::4]))
+print("mean cycles from ticket to first body:", int(rec[..., 2].mean()), " epilogue:", int(rec[..., 3].mean()), " (by cb:",
+      " ".join(str(int(x)) for x in rec[..., 2].mean(0)[::8]), ")")
