@@ -106,6 +106,13 @@ __device__ __forceinline__ void fused_load_vfrag(const char* v0, const char* v1)
                  : "memory", "v255");
 }
 
+template <int T>
+__device__ __forceinline__ void fused_acc_zero(u32x4 z)
+{
+    // (the compiler does not know this statement is an MFMA: the wait states between its writes of z and the read are ours)
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[%c1:%c2], %0, %0, 0" : : "v"(z), "i"(16 * T), "i"(16 * T + 15) : FA2_ACC_CLOBBERS);
+}
+
 template <int DQT>
 __device__ __forceinline__ void fused_dq_zero()
 {
@@ -293,10 +300,11 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
             for (int j = wave; j < 256 / RPI; j += 4)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (fused_lptr_t)(smem + j * 1024), 16, doff, (cb * 256 + j * RPI) * ROWB, 0, 0);
         }
-        static_for<32 * DT>([&](auto R) {
-            acc_write<decltype(R)::value>(0.0f);
-            acc_write<128 + decltype(R)::value>(0.0f);
-        });
+        // dK^T, dV^T <- 0: sixteen MFMAs on a zero fragment instead of 256 accumulator writes
+        {
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            static_for<16>([&](auto T) { fused_acc_zero<decltype(T)::value>(z); });
+        }
 
         // ---- LDS-DMA staging of a 32-row Q / dO tile + its row constants into ring slot `buf`
         const auto q_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Qh, 0, N * ROWB, 0x00020000);
@@ -387,21 +395,31 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
         // lane indices recomputed here so that nothing per-lane has to live (or spill) across the loop
         const int lane_ep = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
         const int ki_ep = lane_ep & 31, h_ep = lane_ep >> 5;
+        // a lane holds 4 consecutive columns of its key per register quad, its partner lane (+32) the next 4: one
+        // v_permlane32_swap per packed dword pairs them up, so that every lane stores 16 contiguous bytes
         static_for<2>([&](auto KB) {
             constexpr int kb = decltype(KB)::value;
             const int key = kw0 + 32 * kb + ki_ep;
-            char* dKk = (char*)p.dK + slab + (size_t)key * ROWB;
-            char* dVk = (char*)p.dV + slab + (size_t)key * ROWB;
-            static_for<4 * DT>([&](auto G) {
-                constexpr int dt = decltype(G)::value / 4, g = decltype(G)::value % 4;
-                constexpr int RK = 16 * (kb * DT + dt) + 4 * g, RV = 128 + 16 * (kb * DT + dt) + 4 * g;
-                bf16x4 a, b;
-                a[0] = (__bf16)(acc_read<RK>() * p.scale); a[1] = (__bf16)(acc_read<RK + 1>() * p.scale);
-                a[2] = (__bf16)(acc_read<RK + 2>() * p.scale); a[3] = (__bf16)(acc_read<RK + 3>() * p.scale);
-                b[0] = (__bf16)acc_read<RV>(); b[1] = (__bf16)acc_read<RV + 1>();
-                b[2] = (__bf16)acc_read<RV + 2>(); b[3] = (__bf16)acc_read<RV + 3>();
-                *reinterpret_cast<bf16x4*>(dKk + 2 * (32 * dt + 8 * g + 4 * h_ep)) = a;
-                *reinterpret_cast<bf16x4*>(dVk + 2 * (32 * dt + 8 * g + 4 * h_ep)) = b;
+            char* dKk = (char*)p.dK + slab + (size_t)key * ROWB + 16 * h_ep;
+            char* dVk = (char*)p.dV + slab + (size_t)key * ROWB + 16 * h_ep;
+            static_for<2 * DT>([&](auto G) {
+                constexpr int dt = decltype(G)::value / 2, gp = decltype(G)::value % 2;
+                constexpr int RK = 16 * (kb * DT + dt) + 8 * gp, RV = 128 + RK;
+                auto pack4 = [&](float a, float b, float c, float d, float sc) {
+                    bf16x4 v;
+                    v[0] = (__bf16)(a * sc); v[1] = (__bf16)(b * sc); v[2] = (__bf16)(c * sc); v[3] = (__bf16)(d * sc);
+                    return __builtin_bit_cast(u32x2, v);
+                };
+                auto emit = [&](u32x2 x, u32x2 y, char* dst) {
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(x[0], y[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(x[1], y[1], false, false);
+                    const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+                    *reinterpret_cast<u32x4*>(dst + 2 * (32 * dt + 16 * gp)) = o;
+                };
+                emit(pack4(acc_read<RK>(), acc_read<RK + 1>(), acc_read<RK + 2>(), acc_read<RK + 3>(), p.scale),
+                     pack4(acc_read<RK + 4>(), acc_read<RK + 5>(), acc_read<RK + 6>(), acc_read<RK + 7>(), p.scale), dKk);
+                emit(pack4(acc_read<RV>(), acc_read<RV + 1>(), acc_read<RV + 2>(), acc_read<RV + 3>(), 1.0f),
+                     pack4(acc_read<RV + 4>(), acc_read<RV + 5>(), acc_read<RV + 6>(), acc_read<RV + 7>(), 1.0f), dVk);
             });
         });
 #ifdef FA2_FUSED_STATS
