@@ -59,7 +59,13 @@ def test_argument_checking_status_codes():
     assert lib.fa2_forward(one, one, one, one, one, 1, 1, 128, 64, -1.0, 0, 0, None) == -2
     assert lib.fa2_forward(one, one, one, one, one, 1, 1, 128, 64, 0.125, 7, 0, None) == -4
     assert lib.fa2_backward(*([one] * 9), 1, 1, 128, 64, 0.125, 0, 0, None, 0, None) == -5
-    assert lib.fa2_backward_workspace_bytes(4, 16, 8192, 128, 0) == 3 * 4 * 16 * 8192 * 4
+    base = 3 * 4 * 16 * 8192 * 4                       # D and the two row-constant planes
+    assert lib.fa2_backward_workspace_bytes(4, 16, 8192, 64, 0) == base          # d = 64: the two-kernel form only
+    assert lib.fa2_backward_workspace_bytes(4, 16, 8192, 128, 1) == base         # fp32
+    fused = lib.fa2_backward_workspace_bytes(4, 16, 8192, 128, 0)                # + fp32 dQ sums + a control block
+    assert base + 4 * 16 * 8192 * 128 * 4 < fused < base + 4 * 16 * 8192 * 128 * 4 + (1 << 20)
+    assert lib.fa2_backward_fused_workspace_bytes(4, 16, 8192, 128) == fused
+    assert lib.fa2_backward_workspace_bytes(4, 16, 8000, 128, 0) == 3 * ((4 * 16 * 8000 * 4 + 255) // 256 * 256)   # N % 256 != 0
     assert b"head_dim" in lib.fa2_status_string(-3)
 
 
