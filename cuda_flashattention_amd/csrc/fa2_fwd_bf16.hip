@@ -309,6 +309,13 @@ __device__ __forceinline__ void fwd_stage_b(float& l_run, uint32_t (&pw)[8], con
 }
 #undef FA2_SOFTMAX_PAIR
 
+template <int R>
+__device__ __forceinline__ void fwd_acc_zero(u32x4 z)
+{
+    // (the compiler does not know this statement is an MFMA: the wait states between its writes of z and the read are ours)
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[%c1:%c2], %0, %0, 0" : : "v"(z), "i"(R), "i"(R + 15) : FA2_ACC128_CLOBBERS);
+}
+
 template <int D, bool CAUSAL, bool STATE>
 __global__ void __launch_bounds__(64 * kFwdWaves, 1) fa2_fwd_bf16_kernel(FwdArgs p)
 {
@@ -363,6 +370,34 @@ __global__ void __launch_bounds__(64 * kFwdWaves, 1) fa2_fwd_bf16_kernel(FwdArgs
     }
     const int niter = ((ntiles + 1 + 2) / 3) * 3;
 
+    // ---- LDS-DMA staging: wave w issues pieces w, w + 8, ... of the 2 * NP pieces of a tile (the
+    // first NP are K, the rest V).  The swizzle term depends on the row modulo 16 only, hence is the
+    // same for all pieces of a wave: one per-lane voffset, everything else wave-uniform (soffset);
+    // rows >= Nk read as zeros.
+    const int drow = lane / CPR;
+    const int dslot = lane % CPR;
+    const int prow = wave * RPI + drow;
+    const int doff = drow * ROWB + 16 * ((lds_off<D>(prow, dslot) - ROWB * prow) >> 4);
+    const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, Nk * ROWB, 0x00020000);
+    const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, Nk * ROWB, 0x00020000);
+    auto stage = [&](int t, int buf) {
+        char* b = smem + buf * TILEB;
+        static_for<PPW>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            constexpr bool isv = (kFwdWaves * i) >= NP;            // wave + 8 i < NP  <=>  8 i < NP
+            const int piece = wave + kFwdWaves * i - (isv ? NP : 0);
+            const int soff = (t * kFwdKV + piece * RPI) * ROWB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(isv ? v_rsrc : k_rsrc, (lds_ptr_t)(b + (isv ? VREG : 0) + piece * 1024),
+                                                     16, doff, soff, 0, 0);
+        });
+    };
+    // ---- prologue DMA first: tiles 0 and 1 into buffers 0 and 1; buffer 2 (read by the first, all-zero-P PV step) must
+    // hold finite data: tile 0 again.  Issued before the Q fragments and the accumulators are set up, so that their
+    // latency runs beside that work instead of after it.
+    stage(0, 0);
+    stage(1, 1);
+    stage(0, 2);
+
     // ---- Q fragments -> AGPRs; lane holds Q[q][16s + 8h .. +7].
     static_for<KS>([&](auto S) {
         constexpr int sidx = decltype(S)::value;
@@ -389,34 +424,14 @@ __global__ void __launch_bounds__(64 * kFwdWaves, 1) fa2_fwd_bf16_kernel(FwdArgs
         mb = m_run == -INFINITY ? 0.0f : m_run * kLog2e;
         thr = (m_run + kRescaleThr) * inv_scale;
     } else {
-        static_for<16 * DT>([&](auto R) { a128_write<A_O + decltype(R)::value>(0.0f); });
+        const u32x4 z = {0u, 0u, 0u, 0u};            // O^T <- 0: DT MFMAs on a zero fragment instead of 16 DT accumulator writes
+        static_for<DT>([&](auto T) { fwd_acc_zero<A_O + 16 * decltype(T)::value>(z); });
         m_run = -INFINITY;
         l_run = 0.0f;
         mb = 0.0f;
         thr = -INFINITY;
     }
 
-    // ---- LDS-DMA staging: wave w issues pieces w, w + 8, ... of the 2 * NP pieces of a tile (the
-    // first NP are K, the rest V).  The swizzle term depends on the row modulo 16 only, hence is the
-    // same for all pieces of a wave: one per-lane voffset, everything else wave-uniform (soffset);
-    // rows >= Nk read as zeros.
-    const int drow = lane / CPR;
-    const int dslot = lane % CPR;
-    const int prow = wave * RPI + drow;
-    const int doff = drow * ROWB + 16 * ((lds_off<D>(prow, dslot) - ROWB * prow) >> 4);
-    const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, Nk * ROWB, 0x00020000);
-    const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, Nk * ROWB, 0x00020000);
-    auto stage = [&](int t, int buf) {
-        char* b = smem + buf * TILEB;
-        static_for<PPW>([&](auto I) {
-            constexpr int i = decltype(I)::value;
-            constexpr bool isv = (kFwdWaves * i) >= NP;            // wave + 8 i < NP  <=>  8 i < NP
-            const int piece = wave + kFwdWaves * i - (isv ? NP : 0);
-            const int soff = (t * kFwdKV + piece * RPI) * ROWB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(isv ? v_rsrc : k_rsrc, (lds_ptr_t)(b + (isv ? VREG : 0) + piece * 1024),
-                                                     16, doff, soff, 0, 0);
-        });
-    };
     auto tile_barrier = [&]() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA has landed ...
         __syncthreads();                                      // ... and so has everyone's
@@ -534,11 +549,7 @@ __global__ void __launch_bounds__(64 * kFwdWaves, 1) fa2_fwd_bf16_kernel(FwdArgs
         FA2_STAMP(dg_r)
     };
 
-    // ---- prologue: tiles 0 and 1 into buffers 0 and 1; buffer 2 (read by the first, all-zero-P
-    // PV step) must hold finite data: tile 0 again.
-    stage(0, 0);
-    stage(1, 1);
-    stage(0, 2);
+    // ---- the prologue tiles (issued at the top) have landed
     tile_barrier();
 #pragma unroll
     for (int sp = 0; sp < 2; ++sp)
@@ -603,21 +614,28 @@ __global__ void __launch_bounds__(64 * kFwdWaves, 1) fa2_fwd_bf16_kernel(FwdArgs
     const size_t qoff = (size_t)head * qhs + qrow;
     const bool fin = !STATE || p.finalize;
     const float inv = fin ? (l_tot > 0.0f ? 1.0f / l_tot : 0.0f) : 1.0f;
-    static_for<4 * DT>([&](auto G) {
-        constexpr int dt = decltype(G)::value / 4, g = decltype(G)::value % 4;
-        constexpr int R = A_O + dt * 16 + 4 * g;
-        f32x4 v;
+    // a lane holds 4 consecutive columns of its row per register quad, its partner lane (+32) the next 4: for the bf16
+    // output one v_permlane32_swap per packed dword pairs them up, so that every lane stores 16 contiguous bytes
+    static_for<2 * DT>([&](auto G) {
+        constexpr int dt = decltype(G)::value / 2, gp = decltype(G)::value % 2;
+        constexpr int R = A_O + dt * 16 + 8 * gp;
+        f32x4 v, w;
         v[0] = a128_read<R>() * inv; v[1] = a128_read<R + 1>() * inv;
         v[2] = a128_read<R + 2>() * inv; v[3] = a128_read<R + 3>() * inv;
-        if (qrow < Nq) {
-            if (fin) {
-                bf16x4 o;
+        w[0] = a128_read<R + 4>() * inv; w[1] = a128_read<R + 5>() * inv;
+        w[2] = a128_read<R + 6>() * inv; w[3] = a128_read<R + 7>() * inv;
+        if (fin) {
+            bf16x4 x, y;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
-                *reinterpret_cast<bf16x4*>((char*)p.O + qoff * ROWB + 2 * (32 * dt + 8 * g + 4 * h)) = o;
-            } else {
-                *reinterpret_cast<f32x4*>(p.Oacc + qoff * D + 32 * dt + 8 * g + 4 * h) = v;
-            }
+            for (int e = 0; e < 4; ++e) { x[e] = (__bf16)v[e]; y[e] = (__bf16)w[e]; }
+            const u32x2 xu = __builtin_bit_cast(u32x2, x), yu = __builtin_bit_cast(u32x2, y);
+            const auto s0 = __builtin_amdgcn_permlane32_swap(xu[0], yu[0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(xu[1], yu[1], false, false);
+            const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+            if (qrow < Nq) *reinterpret_cast<u32x4*>((char*)p.O + qoff * ROWB + 2 * (32 * dt + 16 * gp + 8 * h)) = o;
+        } else if (qrow < Nq) {
+            *reinterpret_cast<f32x4*>(p.Oacc + qoff * D + 32 * dt + 16 * gp + 4 * h) = v;
+            *reinterpret_cast<f32x4*>(p.Oacc + qoff * D + 32 * dt + 16 * gp + 8 + 4 * h) = w;
         }
     });
 #ifdef FA2_DIAG_BLOCKS
