@@ -43,6 +43,7 @@ COST = {"lds": 4, "valu": 4, "exp": 8, "cvt": 4, "mask": 16}
 READ_AHEAD = 7           # issue a fragment read this many MFMAs before its consumer ...
 READ_LATEST = 4          # ... and not later than this many
 NSLOT = 7
+WAIT_AGE = int(os.environ.get("FA2_GEN_WAIT_AGE", "3"))
 WAIT_LOOK = int(os.environ.get("FA2_GEN_WAIT_LOOK", "0"))       # see render_lines; 2 was MEASURED 2-3 % slower (fused backward)
 
 
@@ -320,6 +321,7 @@ def render_lines(mfma, per_gap, NS):
         return own, nxt
 
     issued = []         # keys in issue order; entries are (period, key)
+    issue_gap = []      # absolute gap (period * NS + g) at which each was issued
     waited_upto = [-1]  # index into `issued` up to which completion is known
     lines = []
     for period in (0, 1):
@@ -336,14 +338,16 @@ def render_lines(mfma, per_gap, NS):
             if cnt is not None and len(issued) - 1 - cnt <= waited_upto[0]:
                 cnt = None
             if cnt is not None and WAIT_LOOK:
-                # experiment: fewer s_waitcnt (each is an issue slot) by letting one wait also cover what the next WAIT_LOOK
-                # MFMAs need, as far as it is in flight.  It halves the waits and is slower: the merged wait stalls on reads
-                # issued only two or three MFMAs earlier.  Off by default.
+                # fewer s_waitcnt: one wait may also cover what the next WAIT_LOOK MFMAs need, as far as those reads have been
+                # in flight for WAIT_AGE MFMAs.  Without the age limit it halves the waits and is 2-3 % SLOWER (the merged
+                # wait stalls on reads issued a moment ago); with it, about 1 % faster in the fused backward, which sets
+                # its own values.  Off (0) for the dQ and dK/dV bodies.
                 for g2 in range(g + 1, g + 1 + WAIT_LOOK):
                     p2 = period + g2 // NS
                     for k in mfma[g2 % NS][1]:
                         hits = [i for i, (p, kk) in enumerate(issued) if kk == k and p == p2]
-                        if hits:
+                        # only reads that have been in flight for WAIT_AGE MFMAs or more: younger ones may not have landed
+                        if hits and issue_gap[hits[-1]] <= period * NS + g - WAIT_AGE:
                             pos = max(pos, hits[-1])
                 cnt = min(len(issued) - 1 - pos, 15)
             if cnt is not None:
@@ -356,11 +360,13 @@ def render_lines(mfma, per_gap, NS):
             for t in own:
                 if t.kind == "lds":
                     issued.append((period, t.key))
+                    issue_gap.append(period * NS + g)
                 if period == 1:
                     lines.append(t.text)
             for t in nxt:
                 if t.kind == "lds":
                     issued.append((period + 1, t.key))
+                    issue_gap.append(period * NS + g)
                 if period == 1:
                     lines.append("@N " + t.text)
     # prologue = the wrapped tasks alone, in the same order
