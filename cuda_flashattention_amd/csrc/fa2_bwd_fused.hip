@@ -49,12 +49,21 @@ struct FusedStep {
     uint32_t dso, lso, qso, rcso, pvo, mso;
     int need, pval;
 };
-template <int BUF, int PAR, int VMW>
+template <int BUF, int PAR, int VMW, bool MASKED>
 __device__ __forceinline__ void fused_cbody(const uint32_t (&roff)[8], const uint32_t (&toff)[8], uint32_t rcv, float c2, uint32_t dqv,
-                                            uint32_t dvo, uint32_t rcvo, uint32_t mw, uint32_t mw2, int wv, const FusedStep& f, int& err)
+                                            uint32_t dvo, uint32_t rcvo, uint32_t mw, uint32_t mw2, int wv, const FusedStep& f, int& err,
+                                            int lo0 = 0, int lo1 = 0)
 {
 #define FA2_FUSED_CASE(B, P)                                                                                                          \
-    if constexpr (BUF == B && PAR == P)                                                                                               \
+    if constexpr (BUF == B && PAR == P && MASKED)                                                                                     \
+        asm volatile(FA2_FUSED_MBODY_B##B##_P##P                                                                                      \
+                     : [err] "+s"(err)                                                                                                \
+                     : FA2_FUSED_OPS, [vm] "i"(VMW), [dqv] "v"(dqv), [drs] "s"(f.drs), [dso] "s"(f.dso), [lrs] "s"(f.lrs), [lso] "s"(f.lso), \
+                       [mw] "s"(mw), [mw2] "s"(mw2), [qrs] "s"(f.qrs), [grs] "s"(f.grs), [rcrs] "s"(f.rcrs), [qso] "s"(f.qso),           \
+                       [rcso] "s"(f.rcso), [dvo] "v"(dvo), [rcvo] "v"(rcvo), [wv] "s"(wv), [ctl] "s"(f.ctl), [pvo] "s"(f.pvo),           \
+                       [mso] "s"(f.mso), [need] "s"(f.need), [pval] "s"(f.pval), [lo0] "v"(lo0), [lo1] "v"(lo1)                        \
+                     : FA2_FUSED_CLOBBERS, "s12", "s13", "scc", "exec", "m0", "v39");                                                 \
+    if constexpr (BUF == B && PAR == P && !MASKED)                                                                                    \
         asm volatile(FA2_FUSED_CBODY_B##B##_P##P                                                                                      \
                      : [err] "+s"(err)                                                                                                \
                      : FA2_FUSED_OPS, [vm] "i"(VMW), [dqv] "v"(dqv), [drs] "s"(f.drs), [dso] "s"(f.dso), [lrs] "s"(f.lrs), [lso] "s"(f.lso), \
@@ -177,7 +186,12 @@ __device__ __forceinline__ bool fused_spin_over(int* ctl, int spins)
 //     E chain then adds to), stores its own, and publishes how far it is in prog[head][j]: the order of the additions is
 //     fixed, so the result is deterministic.  A unit only ever waits for units taken from the same queue before it, and
 //     the workgroup holding the oldest unfinished unit never waits: no deadlock for any number of resident workgroups.
-template <bool CHAIN>
+//   CAUSAL (chained form only, square, no shift): key block cb sees the query sub-tiles t >= 8 cb, the first eight of them
+//     through a mask.  Everything runs on the REVERSED sub-tile index: every key block starts at the last sub-tile and walks
+//     down to its diagonal, so all of a head's workgroups start at once; the sum of a sub-tile starts at the key block on
+//     whose diagonal it lies and is handed DOWN to key block 0, which holds every final sum.  Units are therefore taken
+//     in descending key-block order (a unit waits only for units taken before it), and the masked bodies are a unit's last.
+template <bool CHAIN, bool CAUSAL>
 __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) fa2_bwd_fused_kernel(FusedArgs fp)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -275,6 +289,7 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
             __syncthreads();
             head = __builtin_amdgcn_readfirstlane(mail[0]);
             cb = __builtin_amdgcn_readfirstlane(mail[1]);
+            if (CAUSAL) cb = ncb - 1 - cb;
             err0 = __builtin_amdgcn_readfirstlane(mail[2]);
             if (head < 0) break;
         } else {
@@ -322,16 +337,22 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
             if (wave < 2 && lane < 32)                   // 32 x -L/scale (wave 0), 32 x -D (wave 1)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rc_rsrc, (fused_lptr_t)(b + 2 * TROWS * ROWB + wave * 128), 4, rcoff, t * TROWS * 4, 0, 0);
         };
-        stage(0, 0);
+        // steps u = 0 .. n_u - 1 of this unit work on sub-tile tl(u); the bodies from `first_masked` on carry the causal mask
+        const int n_u = CAUSAL ? ntiles - 8 * cb : ntiles;
+        const int niter_u = CAUSAL ? ((n_u + 1 + 5) / 6) * 6 : niter;
+        const int first_masked = CAUSAL ? ((n_u - 8) / 6) * 6 : niter_u;
+        auto tl = [&](int u) { return CAUSAL ? ntiles - 1 - u : u; };
+        stage(tl(0), 0);
         fused_dq_zero<DQT>();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                 // V fragments, K image and the first tile have landed
         asm volatile(FA2_FUSED_PRO : : FA2_FUSED_OPS, [vm] "i"(VMW) : FA2_FUSED_CLOBBERS);
 
         const auto dq_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(fp.dQacc + (size_t)head * N * D), 0, N * D * 4, 0x00020000);
-        const int* const prev = prog_base + head * ncb + cb - 1;      // the key block this one takes the running sums from (cb > 0)
-        const int prev_off = (int)((prev - fp.ctl) * 4);
         int* const mine = prog_base + head * ncb + cb;
+        const int* const prev = mine + (CAUSAL ? 1 : -1);             // the key block this one takes the running sums from
+        const int prev_off = (int)((prev - fp.ctl) * 4);
+        const int mine_off = (int)((mine - fp.ctl) * 4);
         if constexpr (CHAIN) fused_seen_set(0);          // what prev was last seen at
         int err = err0;                                  // raised by a body whose wait for the previous key block ran out
 #ifdef FA2_FUSED_STATS
@@ -340,29 +361,38 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
 #endif
 
         const auto null_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)fp.dQacc, 0, 0, 0x00020000);     // every access out of range
-        auto step = [&](auto BUF, auto PAR, int t) {
+        auto step = [&](auto BUF, auto PAR, auto MASKED, int t) {
             constexpr int buf = decltype(BUF)::value, par = decltype(PAR)::value;
+            constexpr bool masked = decltype(MASKED)::value;
             if constexpr (CHAIN) {
-                // body t: DMA of sub-tile t + 1; E forms the dQ tile of sub-tile t - 1 on top of the running sum loaded by body
-                // t - 1 and stores it; behind the barrier it publishes "t sub-tiles out", waits until key block cb - 1 has
-                // published t + 1, and loads the running sum of sub-tile t
+                // body of step t: DMA of the sub-tile of step t + 1; E forms the dQ tile of the sub-tile of step t - 1 on top of
+                // the running sum loaded by body t - 1 and stores it; behind the barrier it publishes "t sub-tiles out", waits
+                // until the previous key block of the chain has published t + 1, and loads the running sum for step t
                 FusedStep f;
-                const bool live = t >= 1 && t <= ntiles;
+                const bool live = t >= 1 && t <= n_u;
+                const bool more = t + 1 < n_u;                                   // step t + 1 has a sub-tile (else: zero rows)
+                const bool has_prev = t < n_u && (CAUSAL ? tl(t) >= 8 * cb + 8 : cb > 0);
                 f.drs = live ? dq_rsrc : null_rsrc;
-                f.lrs = cb > 0 && !(FA2_FUSED_DIAG & 2) ? dq_rsrc : null_rsrc;
-                f.dso = (uint32_t)__builtin_amdgcn_readfirstlane((t - 1) * TROWS * D * 4);
-                f.lso = f.dso + TROWS * D * 4;
+                f.lrs = has_prev && !(FA2_FUSED_DIAG & 2) ? dq_rsrc : null_rsrc;
+                f.dso = (uint32_t)__builtin_amdgcn_readfirstlane(tl(t - 1) * TROWS * D * 4);
+                f.lso = (uint32_t)__builtin_amdgcn_readfirstlane(tl(t) * TROWS * D * 4);
                 f.qrs = q_rsrc; f.grs = g_rsrc; f.rcrs = rc_rsrc; f.ctl = ctl_rsrc;
-                f.qso = (uint32_t)((t + 1) * TROWS * ROWB + wave * 1024);
-                f.rcso = (uint32_t)((t + 1) * TROWS * 4);
-                f.pvo = (uint32_t)prev_off; f.mso = (uint32_t)prev_off + 4;
-                f.need = (cb > 0 && t < ntiles && !err && !(FA2_FUSED_DIAG & 1)) ? t + 1 : (int)0x80000000;
-                f.pval = t < ntiles ? t : ntiles;
+                f.qso = more ? (uint32_t)(tl(t + 1) * TROWS * ROWB + wave * 1024) : 0x40000000u;      // out of range: zeros
+                f.rcso = more ? (uint32_t)(tl(t + 1) * TROWS * 4) : 0x40000000u;
+                f.pvo = (uint32_t)prev_off; f.mso = (uint32_t)mine_off;
+                f.need = (has_prev && !err && !(FA2_FUSED_DIAG & 1)) ? t + 1 : (int)0x80000000;
+                f.pval = t < n_u ? t : n_u;
+                int lo0 = 0, lo1 = 0;
+                if constexpr (masked) {      // key - 32 tile - 4 h for the lane's two keys (recomputed: nothing per-lane is kept)
+                    const int lane_m = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+                    lo0 = kw0 + (lane_m & 31) - 4 * (lane_m >> 5) - TROWS * tl(t);
+                    lo1 = lo0 + 32;
+                }
 #ifdef FA2_FUSED_STATS2
                 const uint64_t b0 = __builtin_readcyclecounter();
 #endif
-                fused_cbody<buf, par, VMW>(roff, toff, rcv, c2, dqv, (uint32_t)doff, (uint32_t)rcoff, lbase + QRING + wave * 1024,
-                                           lbase + QRING + wave * 128, wave, f, err);
+                fused_cbody<buf, par, VMW, masked>(roff, toff, rcv, c2, dqv, (uint32_t)doff, (uint32_t)rcoff, lbase + QRING + wave * 1024,
+                                                   lbase + QRING + wave * 128, wave, f, err, lo0, lo1);
 #ifdef FA2_FUSED_STATS2
                 st_cycles += (int)(__builtin_readcyclecounter() - b0);       // cycles inside the bodies (reported as "waited")
 #endif
@@ -376,13 +406,22 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
                 fused_dq_zero<DQT>();
             }
         };
-        for (int t = 0; t < niter; t += 6) {
-            step(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, t);
-            step(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, t + 1);
-            step(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, t + 2);
-            step(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, t + 3);
-            step(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, t + 4);
-            step(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, t + 5);
+        auto six = [&](auto MASKED, int t) {
+            step(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, MASKED, t);
+            step(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, MASKED, t + 1);
+            step(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, MASKED, t + 2);
+            step(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, MASKED, t + 3);
+            step(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, MASKED, t + 4);
+            step(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, MASKED, t + 5);
+        };
+        if constexpr (!CAUSAL) {
+#pragma unroll 1
+            for (int t = 0; t < niter_u; t += 6) six(std::false_type{}, t);
+        } else {
+#pragma unroll 1
+            for (int t = 0; t < first_masked; t += 6) six(std::false_type{}, t);
+#pragma unroll 1
+            for (int t = first_masked; t < niter_u; t += 6) six(std::true_type{}, t);
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         if constexpr (CHAIN)
@@ -475,8 +514,9 @@ size_t bwd_fused_ctl_bytes(int BH, int N) { return (size_t)(kCtlHeadmap + 16 * (
 
 hipError_t launch_bwd_fused_bf16(const BwdArgs& a, float* dQacc, int* ctl, int mode, hipStream_t stream)
 {
-    if (a.d != 128 || a.causal || a.Nq != a.Nk || a.Nk % 256 != 0 || a.q_hs != a.Nq || a.k_hs != a.Nk || a.q_row0 != 0)
+    if (a.d != 128 || a.Nq != a.Nk || a.Nk % 256 != 0 || a.q_hs != a.Nq || a.k_hs != a.Nk || a.q_row0 != 0)
         return hipErrorInvalidValue;
+    if (a.causal && (mode != 1 || a.causal_shift != 0)) return hipErrorInvalidValue;
     hipError_t e = hipSuccess;
     if (a.phases & 1) {
         BwdArgs d = a;
@@ -493,9 +533,9 @@ hipError_t launch_bwd_fused_bf16(const BwdArgs& a, float* dQacc, int* ctl, int m
         e = hipMemsetAsync(dQacc, 0, elems * 4, stream);
         if (e != hipSuccess) return e;
         static bool set_f[64] = {};
-        e = ensure_dynamic_lds(fa2_bwd_fused_kernel<false>, lds, set_f);
+        e = ensure_dynamic_lds(fa2_bwd_fused_kernel<false, false>, lds, set_f);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(fa2_bwd_fused_kernel<false>, dim3((unsigned)units), dim3(256), lds, stream, fa);
+        hipLaunchKernelGGL((fa2_bwd_fused_kernel<false, false>), dim3((unsigned)units), dim3(256), lds, stream, fa);
     } else {
         static int cus[64] = {};
         int dev = 0;
@@ -508,10 +548,17 @@ hipError_t launch_bwd_fused_bf16(const BwdArgs& a, float* dQacc, int* ctl, int m
         }
         e = hipMemsetAsync(ctl, 0, bwd_fused_ctl_bytes(a.BH, a.Nk), stream);
         if (e != hipSuccess) return e;
-        static bool set_t[64] = {};
-        e = ensure_dynamic_lds(fa2_bwd_fused_kernel<true>, lds, set_t);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(fa2_bwd_fused_kernel<true>, dim3((unsigned)(units < cus[dev] ? units : cus[dev])), dim3(256), lds, stream, fa);
+        static bool set_t[64] = {}, set_c[64] = {};
+        const dim3 grid((unsigned)(units < cus[dev] ? units : cus[dev]));
+        if (a.causal) {
+            e = ensure_dynamic_lds(fa2_bwd_fused_kernel<true, true>, lds, set_c);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((fa2_bwd_fused_kernel<true, true>), grid, dim3(256), lds, stream, fa);
+        } else {
+            e = ensure_dynamic_lds(fa2_bwd_fused_kernel<true, false>, lds, set_t);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((fa2_bwd_fused_kernel<true, false>), grid, dim3(256), lds, stream, fa);
+        }
     }
     e = hipGetLastError();
     if (e != hipSuccess) return e;

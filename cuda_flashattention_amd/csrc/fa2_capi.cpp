@@ -209,15 +209,15 @@ int fa2_backward_phases(const void* Q, const void* K, const void* V, const void*
         return FA2_ERR_WORKSPACE;
     if (dtype == FA2_DTYPE_BF16) {
         // phases: 1 = D and the row constants, 2 = dQ kernel, 4 = dK/dV kernel, 8 = the single five-product kernel + its
-        // output pass.  7 ("all of it") takes the single kernel where the shape allows (non-causal, d = 128, seq_len % 256 == 0)
-        const bool fused_ok = bwd_fused_shape(seq_len, head_dim, dtype) && !causal;
+        // output pass.  7 ("all of it") takes the single kernel where the shape allows (d = 128, seq_len % 256 == 0)
+        const bool fused_ok = bwd_fused_shape(seq_len, head_dim, dtype);
         if ((phases & 8) && !fused_ok) return FA2_ERR_UNSUPPORTED;
         if ((phases & 8) || (phases == 7 && fused_ok && bwd_fused_allowed())) {
             fa2::BwdArgs a{};
             a.Q = Q; a.K = K; a.V = V; a.O = O; a.dO = dO; a.L = L; a.dQ = dQ; a.dK = dK; a.dV = dV;
             a.D = (float*)workspace; a.BH = B * H; a.Nq = seq_len; a.Nk = seq_len; a.d = head_dim;
             a.RC = (float*)((char*)workspace + align256((size_t)B * H * seq_len * sizeof(float)));
-            a.q_hs = seq_len; a.k_hs = seq_len; a.q_row0 = 0; a.scale = softmax_scale; a.causal = 0; a.causal_shift = 0;
+            a.q_hs = seq_len; a.k_hs = seq_len; a.q_row0 = 0; a.scale = softmax_scale; a.causal = causal ? 1 : 0; a.causal_shift = 0;
             a.phases = phases == 7 ? 9 : (phases & 9);
             char* acc = (char*)workspace + bwd_base_ws(B, H, seq_len);
             return hip_status(fa2::launch_bwd_fused_bf16(a, (float*)acc, (int*)(acc + align256((size_t)B * H * seq_len * head_dim * 4)), 1,

@@ -1,6 +1,6 @@
 """GPU: the single-kernel (five-product) backward of csrc/fa2_bwd_fused.hip, through the C ABI.
 
-fa2_backward takes it for bf16, head_dim 128, non-causal, seq_len % 256 == 0; everything else stays on the dQ and dK/dV
+fa2_backward takes it for bf16, head_dim 128, seq_len % 256 == 0 (causal or not); everything else stays on the dQ and dK/dV
 kernels.  Checked here:
   * against the CPU oracle (rel-L2 <= 5e-3 per tensor, the bf16 bar of test_gpu_parity.py), for both ways of summing dQ
     over the key blocks (mode 1: ordered hand-off -- what fa2_backward uses; mode 0: fp32 atomics);
@@ -9,6 +9,8 @@ kernels.  Checked here:
   * mode 1 is bit-reproducible run to run (no floating-point atomics; the order of the additions is fixed);
   * chains longer than an XCD has CUs (seq_len 16384: 64 key blocks), head counts that are not a multiple of the XCD count,
     more heads than the grid has workgroups;
+  * the causal form (reversed sub-tile order, sums handed down to key block 0, masked bodies around the diagonal) against
+    the oracle, against the two-kernel form, and run to run;
   * the dispatch of fa2_backward / fa2_backward_phases and the status codes of the explicit entry point."""
 import ctypes
 
@@ -147,6 +149,51 @@ def test_bench_shape_matches_the_two_kernel_form():
     assert float((a[0].float() - b[0].float()).norm() / b[0].float().norm()) <= 1e-3
 
 
+@pytest.mark.parametrize("B,H,N", [
+    (1, 1, 256),       # one key block: every body masked, no hand-off
+    (1, 2, 512),       # two key blocks: a chain of two for the last eight sub-tiles
+    (2, 8, 1024),
+    (1, 3, 768),       # unit lengths 8, 16, 24 sub-tiles: masked region not aligned to the six-body loop
+    (1, 9, 2048),
+    (1, 2, 16384),     # 64 key blocks per head
+])
+def test_causal_fused_backward(B, H, N):
+    """Causal, through fa2_backward: vs the oracle (rel-L2 <= 5e-3), bit-reproducible, and within bf16 rounding of the
+    two-kernel form (whose sums over the query tiles run in the opposite order: no bit equality here)."""
+    import oracle
+    fa = _fa()
+    d = 128
+    small = N <= 2048
+    if small:
+        host = [make(B, H, N, d, 7 * N + i, 0.4 if i == 3 else 1.0) for i in range(4)]
+        dev = [t.cuda() for t in host]
+    else:
+        g = torch.Generator(device="cuda").manual_seed(N)
+        dev = [((torch.rand(B, H, N, d, device="cuda", generator=g) - 0.5) * (0.4 if i == 3 else 1.0)).bfloat16() for i in range(4)]
+    scale = d ** -0.5
+    O, L = fa.flash_attention_2_forward(dev[0], dev[1], dev[2], scale, causal=True)
+    ws = torch.empty(fa._capi.lib().fa2_backward_workspace_bytes(B, H, N, d, 0), dtype=torch.uint8, device="cuda")
+    a = [torch.empty_like(dev[0]) for _ in range(3)]
+    b = [torch.empty_like(dev[0]) for _ in range(3)]
+    c = [torch.empty_like(dev[0]) for _ in range(3)]
+    fa.flash_attention_2_backward(dev[0], dev[1], dev[2], O, L, dev[3], scale, causal=True, dQ=a[0], dK=a[1], dV=a[2], workspace=ws)
+    ws.fill_(0xa5)
+    fa.flash_attention_2_backward(dev[0], dev[1], dev[2], O, L, dev[3], scale, causal=True, dQ=b[0], dK=b[1], dV=b[2], workspace=ws)
+    for ph in (1, 6):
+        fa.flash_attention_2_backward(dev[0], dev[1], dev[2], O, L, dev[3], scale, causal=True, dQ=c[0], dK=c[1], dV=c[2], workspace=ws,
+                                      phases=ph)
+    torch.cuda.synchronize()
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    for name, x, y in zip(("dQ", "dK", "dV"), a, c):
+        assert np.isfinite(f32(x)).all(), name
+        assert rel(f32(x), f32(y).astype(np.float64)) <= 1.5e-3, (name, rel(f32(x), f32(y).astype(np.float64)))
+    if small:
+        want = oracle.attention_backward(*[f32(t) for t in host], scale, causal=True)
+        for name, x, w in zip(("dQ", "dK", "dV"), a, want):
+            assert rel(f32(x), w) <= BF16_REL, (name, rel(f32(x), w))
+
+
 def test_status_codes():
     lib = _fa()._capi.lib()
     x = torch.zeros(1, 1, 256, 128, dtype=torch.bfloat16, device="cuda")
@@ -161,5 +208,7 @@ def test_status_codes():
     assert call(256, 128, 2, ws.numel()) != 0          # no such mode
     assert call(256, 128, 1, 1024) != 0                # workspace too small
     # bit 3 of fa2_backward_phases on a shape the single kernel does not take
-    st = lib.fa2_backward_phases(P(x), P(x), P(x), P(x), P(l), P(x), P(x), P(x), P(x), 1, 1, 256, 128, 0.1, 0, 1, P(ws), ws.numel(), None, 8)
-    assert st != 0                                     # causal
+    x64 = torch.zeros(1, 1, 256, 64, dtype=torch.bfloat16, device="cuda")
+    st = lib.fa2_backward_phases(P(x64), P(x64), P(x64), P(x64), P(l), P(x64), P(x64), P(x64), P(x64), 1, 1, 256, 64, 0.1, 0, 0, P(ws),
+                                 ws.numel(), None, 8)
+    assert st != 0                                     # head_dim 64

@@ -131,21 +131,24 @@ def test_fused_backward_kernel(asm):
     buffers x two dS tiles), the chained form's bodies carry their four dQ stores in front of the barrier and the four
     running-sum loads behind it, and nothing in the loop touches scratch."""
     ks = {n: k for n, k in _kernels(asm["fa2_bwd_fused"]).items() if "fa2_bwd_fused_kernelILb" in n}
-    assert len(ks) == 2
+    assert len(ks) == 3          # <atomics>, <chain>, <chain, causal>
     pat = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
     for name, k in ks.items():
-        chain = "ILb1E" in name
+        chain, causal = "ILb1ELb" in name, "ILb1ELb1E" in name
         outside, blocks = _split_asm(k["body"])
         for s in outside:
             for m in pat.finditer(s):
                 hi = int(m.group(1)) if m.group(1) else int(m.group(3))
                 assert hi < 39, (name, s)
         assert k["meta"]["total"] == 512 and k["meta"]["agpr"] == 256, (name, k["meta"])
-        loop = _main_loop(k["body"])
-        assert sum("v_mfma_f32_32x32x16_bf16" in l for l in loop) == 6 * 80, name
-        assert not any("scratch_" in l for l in loop), name
-        bodies = [b for b in _split_asm(loop)[1] if sum("v_mfma" in s for s in b) == 80]
-        assert len(bodies) == 6
+        if causal:       # two inner loops of six bodies (plain, masked) inside the unit loop, + the 16 accumulator-zeroing MFMAs
+            assert sum("v_mfma_f32_32x32x16_bf16" in l for l in k["body"]) == 12 * 80 + 16, name
+        else:
+            assert sum("v_mfma_f32_32x32x16_bf16" in l for l in _main_loop(k["body"])) == 6 * 80, name
+        assert not any("scratch_" in l for l in k["body"]), name
+        bodies = [b for b in _split_asm(k["body"])[1] if sum("v_mfma" in s for s in b) == 80]
+        assert len(bodies) == (12 if causal else 6)          # causal: a second loop of six bodies that carry the mask
+        assert sum(any(s.startswith("v_cmp_le_i32 vcc") for s in b) for b in bodies) == (6 if causal else 0)
         for b in bodies:
             st = [i for i, s in enumerate(b) if s.startswith("buffer_store_dwordx4")]
             ld = [i for i, s in enumerate(b) if s.startswith("buffer_load_dwordx4 v[")]          # running sums (not the LDS-DMA)
@@ -218,8 +221,8 @@ def test_generated_bodies_pass_the_static_checker(inc):
     cb = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(cb)
     text = open(os.path.join(CSRC, inc)).read()
-    names = re.findall(r"#define (FA2_\w+_C?BODY_\w+) ", text)
-    assert len(names) in (12, 16)
+    names = re.findall(r"#define (FA2_\w+_[CM]?BODY_\w+) ", text)
+    assert len(names) in (12, 16, 18)
     for n in names:
         assert cb.check(cb.body(text, n), n) == []
 

@@ -112,7 +112,7 @@ def check(lines, label):
 
 def main():
     text = open(sys.argv[1]).read()
-    names = sys.argv[2:] or re.findall(r"#define (FA2_\w+_C?BODY_\w+) ", text)
+    names = sys.argv[2:] or re.findall(r"#define (FA2_\w+_[CM]?BODY_\w+) ", text)
     bad = 0
     for n in names:
         e = check(body(text, n), n)

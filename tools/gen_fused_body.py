@@ -25,6 +25,7 @@ Two families: FA2_FUSED_BODY_* (the dQ tile is left in DQT for the kernel) and F
 itself stores the finished tile, loads the next running sum, issues the next tile's LDS-DMA, and does the hand-shake with
 the neighbouring key blocks; extra operands %[dqv], %[drs], %[dso], %[lrs], %[lso] (dQ tiles), %[mw], %[mw2], %[qrs], %[grs],
 %[rcrs], %[qso], %[rcso], %[dvo], %[rcvo], %[wv] (DMA), %[ctl], %[pvo], %[mso], %[need], %[pval], %[err] (progress words)).
+FA2_FUSED_MBODY_* = CBODY + the causal mask behind each exponential (operands %[lo0], %[lo1]).
 Operands: %[r*], %[t*] (Q/dO ring addresses), %[rc], %[c2] (scale * log2 e; %[c2p], the same in both halves of an
 SGPR pair, with FA2_GEN_PK=1), %[vm] (immediate: how many of the kernel's vector-memory
 operations may still be in flight when the E chain starts -- those issued after its loads into DQT; 63 = no such loads).
@@ -55,7 +56,7 @@ BUFB = 2 * 32 * ROWB + 256        # Q tile | dO tile | 32 x (-L/scale), 32 x (-D
 DSB = QRING + 3 * BUFB            # two dS tiles of 256 keys x 32 q bf16
 DSTILE = 256 * 64
 LDS_BYTES = DSB + 2 * DSTILE
-COST = dict(COST, ldsw=6, vmem=10)
+COST = dict(COST, ldsw=6, vmem=10, cmask=8)
 
 
 def vf(kb, s): b = VF + 4 * (kb * KS + s); return f"v[{b}:{b + 3}]"
@@ -80,7 +81,7 @@ DQTILE = f"v[{DQT}:{DQT + 15}]"
 PK = os.environ.get("FA2_GEN_PK", "0") == "1"
 
 
-def build(chain=False):
+def build(chain=False, masked=False):
     NS = 80
     gA1, gB, gC, gD = KS + 1, 16, 48, 64
     # B (dP', one dO fragment per pair of MFMAs: light on the LDS) and E (four transposed reads per MFMA: with all four
@@ -198,6 +199,12 @@ def build(chain=False):
                 for r in (r0, r0 + 1):
                     m = m2 or valu(f"v_mul_f32 {sreg(kb, r)}, %[c2], {sreg(kb, r)}", "valu", rel_exp, use_pf - 5)
                     e = valu(f"v_exp_f32 {sreg(kb, r)}, {sreg(kb, r)}", "exp", rel_exp, use_pf - 4, after=[m])
+                    if masked:
+                        # causal: P = 0 where the lane's key lies above the row.  Row of register r within the sub-tile =
+                        # (r & 3) + 8 (r >> 2) + 4 h; %[lo<kb>] (per lane) = key - 32 tile - 4 h: keep iff row >= key
+                        rr = (r & 3) + 8 * (r >> 2)
+                        e = valu(f"v_cmp_le_i32 vcc, %[lo{kb}], {rr}\n\tv_cndmask_b32 {sreg(kb, r)}, 0, {sreg(kb, r)}, vcc", "cmask", rel_exp,
+                                 use_pf - 3, after=[e])
                     exps[r] = e
                     pair.append(e)
                 valu(f"v_cvt_pk_bf16_f32 {pfw(kb, sp, j)}, {sreg(kb, 8 * sp + 2 * j)}, {sreg(kb, 8 * sp + 2 * j + 1)}", "cvt", rel_exp,
@@ -370,8 +377,15 @@ def main():
     cper_gap, cload = base.place(ct, NS)
     clines, cpro = render_lines(cm, cper_gap, NS)
     assert cpro == pro
+    # the causal kernel's bodies for the tiles around the diagonal: rare (at most 18 per unit), so they may run over the
+    # issue budget of a gap; what they leave in flight for the next body is the same as the plain ones' (they alternate)
+    mm, mt, _ = build(chain=True, masked=True)
+    mper_gap, mload = base.place(mt, NS, budget=base.GAP_BUDGET + 8)
+    mlines, mpro = render_lines(mm, mper_gap, NS)
+    assert mpro == pro
     if args.check:
         print("   chained load:", " ".join(str(l) for l in cload))
+        print("   masked  load:", " ".join(str(l) for l in mload))
         print(f"fused D=128: {len(lines)} lines, {sum('v_mfma' in l for l in lines)} MFMAs, {len(pro)} early, max gap load {max(load)}, "
               f"{sum(l > base.GAP_BUDGET for l in load)} of {NS} gaps over {base.GAP_BUDGET}")
         print("   load:", " ".join(str(l) for l in load))
@@ -388,6 +402,7 @@ def main():
         for par in range(2):
             chunks.append(f"#define FA2_FUSED_BODY_B{buf}_P{par} \\\n" + base.c_string(resolve(lines, buf, par)) + "\n")
             chunks.append(f"#define FA2_FUSED_CBODY_B{buf}_P{par} \\\n" + base.c_string(resolve(clines, buf, par, chain=True)) + "\n")
+            chunks.append(f"#define FA2_FUSED_MBODY_B{buf}_P{par} \\\n" + base.c_string(resolve(mlines, buf, par, chain=True)) + "\n")
     with open(args.out, "w") as f:
         f.write("\n".join(chunks))
     print("wrote", args.out)
