@@ -230,6 +230,16 @@ def main():
                 return {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1), "timing": "median of 3 x 20 launches after 50 warm-up launches"}
             extra["fwd_bf16_cfg2_(4,16,4096,64)"] = fwd_only(4, 16, 4096, 64, torch.bfloat16, False)
             extra["fwd_fp8_e4m3_causal_cfg5_(1,16,32768,128)"] = fwd_only(1, 16, 32768, 128, torch.float8_e4m3fn, True)
+            # the headline shape with a causal mask (past the reference, which has none): forward + backward, 7 B H N^2 d flops
+            def causal_step():
+                fa.flash_attention_2_forward(Q, K, V, scale, causal=True, O=O, L=L)
+                fa.flash_attention_2_backward(Q, K, V, O, L, dO, scale, causal=True, dQ=dQ, dK=dK, dV=dV, workspace=ws)
+            for _ in range(10):
+                causal_step()
+            msc = median_ms(causal_step, torch, 3, 10)
+            extra["fwd_bwd_bf16_causal_(4,16,8192,128)"] = {"ms": round(msc, 4), "tflops": round(7.0 * B * H * N * N * D / msc / 1e9, 1),
+                                                            "timing": "median of 3 x 10 steps after 10 warm-up steps"}
+            fwd()                                                    # leave O, L as the non-causal forward's
             # the reference's FlashAttention-1 step restated (scalar fp32, one head, no MFMA): a DIDACTIC row, not a target
             Nf, df = 4096, 64
             qf, kf, vf = (torch.rand(Nf, df, device=dev) - 0.5 for _ in range(3))

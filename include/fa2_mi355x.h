@@ -106,7 +106,7 @@ size_t fa2_backward_workspace_bytes(int B, int H, int seq_len, int head_dim, int
 /* dQ, dK, dV from Q, K, V, O, L (forward outputs) and dO.  Deterministic: no floating-point atomics, every
  * gradient element is summed in a fixed order (the reference's smem + global atomicAdd scheme,
  * flash_attention_backward_kernel.cu:208-231, is not reproduced).  Two implementations behind this call:
- *   - bf16, head_dim 128, non-causal, seq_len a multiple of 256: ONE kernel that forms the five block products once
+ *   - bf16, head_dim 128, seq_len a multiple of 256 (causal or not): ONE kernel that forms the five block products once
  *     (csrc/fa2_bwd_fused.hip); a workgroup owns 256 keys (dK, dV in registers) and the dQ tiles are summed key block
  *     after key block in a fixed order through the L2 of the XCD the head is pinned to;
  *   - everything else: a dQ kernel and a dK/dV kernel (seven products, csrc/fa2_bwd_bf16.hip).
@@ -147,7 +147,7 @@ int fa2_backward_block(const void* Q, const void* K, const void* V, const void* 
 /* The single-kernel five-product backward (csrc/fa2_bwd_fused.hip) with the way dQ is summed over the key-block
  * workgroups of a head chosen by the caller -- mode 1: handed from key block to key block in a fixed order by a
  * persistent grid (deterministic; what fa2_backward uses), mode 0: fp32 atomics (NOT bit-reproducible; kept as the
- * measured alternative).  bf16, d = 128, non-causal, seq_len a multiple of 256;
+ * measured alternative).  bf16, d = 128, non-causal (fa2_backward also takes the causal case), seq_len a multiple of 256;
  * FA2_ERR_UNSUPPORTED otherwise.  Workspace: fa2_backward_fused_workspace_bytes (= fa2_backward_workspace_bytes). */
 size_t fa2_backward_fused_workspace_bytes(int B, int H, int seq_len, int head_dim);
 int fa2_backward_fused(const void* Q, const void* K, const void* V, const void* O, const float* L,
