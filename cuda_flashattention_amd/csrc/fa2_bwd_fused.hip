@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
     constexpr int CPR = 16, RPI = 4, NINS = TROWS / RPI;      // 8 one-KiB DMA pieces per tensor per 32-row tile
     constexpr int VF = FA2_FUSED_VF, DQT = FA2_FUSED_DQT, ROFFK = FA2_FUSED_ROFFK, DSWR = FA2_FUSED_DSWR, DSRD = FA2_FUSED_DSRD,
                   KT = FA2_FUSED_KT;
-    constexpr int VMW = CHAIN ? 5 : 63;              // vector-memory operations issued behind the DQT loads: >= 4 DMA pieces, flag load
+    constexpr int VMW = CHAIN ? 4 : 63;              // vector-memory operations issued behind the DQT loads and in front of the E chain: >= 4 DMA pieces
     int* const mail = reinterpret_cast<int*>(smem + FA2_FUSED_LDS);      // 16 bytes behind the generated map: the unit taken
 
     const int tid = threadIdx.x;

@@ -269,7 +269,10 @@ def build(chain=False, masked=False):
         tasks.append(Task(f"s_cmp_lt_u32 %[wv], 2\n\ts_cbranch_scc0 4f\n\ts_mov_b64 exec, 0xffffffff\n\ts_add_u32 m0, %[mw2], @NB+{2 * 32 * ROWB}\n\t"
                           "s_nop 0\n\tbuffer_load_dword %[rcvo], %[rcrs], %[rcso] offen lds\n\ts_mov_b64 exec, -1\n\t4:", COST["vmem"] + 6, 1, 12,
                           "vmem", ("dma", "rc")))
-        tasks.append(Task("buffer_load_dword v39, off, %[ctl], %[pvo] sc1", COST["vmem"], 1, 12, "vmem", ("seen",)))
+        # the progress prefetch is issued late (its round trip is ~900 clocks, the barrier behind which it is read sits at
+        # gap 72): the staler the prefetched word, the further behind its predecessor a key block has to run
+        pg = int(os.environ.get("FA2_GEN_SEEN_GAP", "42"))
+        tasks.append(Task("buffer_load_dword v39, off, %[ctl], %[pvo] sc1", COST["vmem"], pg, pg + 4, "vmem", ("seen",)))
         st = [Task(f"buffer_store_dwordx4 v[{DQT + 4 * g}:{DQT + 4 * g + 3}], %[dqv], %[drs], %[dso] offen offset:{1024 * g}", COST["vmem"],
                    gEend + 3, gEend + 8, "vmem", ("dqst", g)) for g in range(4)]
         tasks.extend(st)
