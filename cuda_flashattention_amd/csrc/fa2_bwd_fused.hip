@@ -10,6 +10,7 @@
 // workgroups of a head.  MODE 0 adds them with fp32 atomics (memory-side on MI355X, ~1.3 TB/s chip-wide: the known
 // floor, B H (N/256) N d 4 bytes); MODE 1 passes a running sum from key block j to key block j + 1 through the L2 of the XCD
 // the head is pinned to (see fused_handoff below).
+#include <cstdlib>
 #include <type_traits>
 
 #include "fa2_common.h"
@@ -549,7 +550,14 @@ hipError_t launch_bwd_fused_bf16(const BwdArgs& a, float* dQacc, int* ctl, int m
         e = hipMemsetAsync(ctl, 0, bwd_fused_ctl_bytes(a.BH, a.Nk), stream);
         if (e != hipSuccess) return e;
         static bool set_t[64] = {}, set_c[64] = {};
-        const dim3 grid((unsigned)(units < cus[dev] ? units : cus[dev]));
+        int wgs = units < cus[dev] ? units : cus[dev];
+        // FA2_FUSED_GRID=<n>: fewer workgroups than CUs (tests: the unit queues must drain with ANY number of resident
+        // workgroups, down to one -- the claim the hand-off's deadlock freedom rests on)
+        if (const char* g = getenv("FA2_FUSED_GRID")) {
+            const int n = atoi(g);
+            if (n >= 1 && n < wgs) wgs = n;
+        }
+        const dim3 grid((unsigned)wgs);
         if (a.causal) {
             e = ensure_dynamic_lds(fa2_bwd_fused_kernel<true, true>, lds, set_c);
             if (e != hipSuccess) return e;

@@ -194,6 +194,36 @@ def test_causal_fused_backward(B, H, N):
             assert rel(f32(x), w) <= BF16_REL, (name, rel(f32(x), w))
 
 
+@pytest.mark.parametrize("causal", [False, True])
+def test_any_number_of_resident_workgroups(causal, monkeypatch):
+    """The hand-off never needs co-residency: a unit only waits for units taken from its queue before it.  With the grid
+    forced down to 1, 2, 3, 5 and 11 workgroups (FA2_FUSED_GRID; 24 units here, up to three per queue in flight) the kernel
+    must finish and produce the SAME BITS as with one workgroup per CU -- a single workgroup walks every unit of every XCD's
+    queue in order, so any unit that waited for a later one would spin into its bounded-poll error (NaNs)."""
+    fa = _fa()
+    B, H, N, d = 1, 3, 2048, 128
+    host, dev, O, L, scale = case(B, H, N, seed=17)
+    if causal:
+        O, L = fa.flash_attention_2_forward(dev[0], dev[1], dev[2], scale, causal=True)
+    ws = torch.empty(fa._capi.lib().fa2_backward_workspace_bytes(B, H, N, d, 0), dtype=torch.uint8, device="cuda")
+
+    def run():
+        out = [torch.empty_like(dev[0]) for _ in range(3)]
+        fa.flash_attention_2_backward(dev[0], dev[1], dev[2], O, L, dev[3], scale, causal=causal, dQ=out[0], dK=out[1], dV=out[2],
+                                      workspace=ws)
+        torch.cuda.synchronize()
+        return out
+
+    monkeypatch.delenv("FA2_FUSED_GRID", raising=False)
+    ref = run()
+    assert all(bool(torch.isfinite(t.float()).all()) for t in ref)
+    for wgs in (1, 2, 3, 5, 11):
+        monkeypatch.setenv("FA2_FUSED_GRID", str(wgs))
+        got = run()
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b), wgs
+
+
 def test_status_codes():
     lib = _fa()._capi.lib()
     x = torch.zeros(1, 1, 256, 128, dtype=torch.bfloat16, device="cuda")

@@ -43,6 +43,31 @@ def test_bf16_forward_backward_random_shapes():
             assert _rel(f(got), ref) <= 5e-3, f"{tag} {name}"
 
 
+def test_bf16_backward_random_shapes_of_the_single_kernel():
+    """The same sweep over the shapes fa2_backward gives to its single five-product kernel: d = 128, seq_len a multiple of
+    256 (1 .. 12 key blocks per head), any batch and head count, causal on and off, value scales that move the softmax."""
+    import cuda_flashattention_amd as fa
+    import oracle
+    f = lambda t: t.float().cpu().numpy()
+    rng = np.random.default_rng(909)
+    for i in range(14):
+        B, H, N = int(rng.integers(1, 3)), int(rng.integers(1, 12)), 256 * int(rng.integers(1, 13))
+        causal, amp = bool(rng.integers(0, 2)), float(rng.choice([0.5, 1.0, 3.0]))
+        d = 128
+        g = torch.Generator().manual_seed(500 + i)
+        mk = lambda s: ((torch.rand(B, H, N, d, generator=g) - 0.5) * s).bfloat16()
+        Q, K, V, dO = mk(amp), mk(amp), mk(1.0), mk(0.4)
+        s = 1.0 / d ** 0.5
+        O, L = fa.flash_attention_2_forward(Q.cuda(), K.cuda(), V.cuda(), s, causal=causal)
+        dQ, dK, dV = fa.flash_attention_2_backward(Q.cuda(), K.cuda(), V.cuda(), O, L, dO.cuda(), s, causal=causal)
+        torch.cuda.synchronize()
+        gr = oracle.attention_backward(f(Q), f(K), f(V), f(dO), s, causal=causal)
+        tag = f"case {i}: B{B} H{H} N{N} causal={causal} amp={amp}"
+        for name, got, ref in (("dQ", dQ, gr[0]), ("dK", dK, gr[1]), ("dV", dV, gr[2])):
+            assert np.isfinite(f(got)).all(), f"{tag} {name}"
+            assert _rel(f(got), ref) <= 5e-3, f"{tag} {name} {_rel(f(got), ref)}"
+
+
 def test_fp8_forward_random_shapes():
     import cuda_flashattention_amd as fa
     import oracle
