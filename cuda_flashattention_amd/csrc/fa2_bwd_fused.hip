@@ -143,6 +143,7 @@ struct FusedArgs {
     float* dQacc;       // fp32 [BH][N][128]: zeroed by the launcher and atomically added to (CHAIN = false);
                         // the running sums as [BH][N / 32][wave][g][lane] x 4 floats (CHAIN = true: fused_dq_out_chain_kernel)
     int* ctl;           // control block (CHAIN = true)
+    int fault;          // fault injection (FA2_FUSED_FAULT=1, tests): key block 1 of every head never publishes its progress
 };
 
 __device__ __forceinline__ int fused_ctl_ints(int BH, int ncb) { return kCtlHeadmap + 16 * (BH + 1) + 9 * BH * ncb; }
@@ -383,6 +384,7 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
                 f.pvo = (uint32_t)prev_off; f.mso = (uint32_t)mine_off;
                 f.need = (has_prev && !err && !(FA2_FUSED_DIAG & 1)) ? t + 1 : (int)0x80000000;
                 f.pval = t < n_u ? t : n_u;
+                if (fp.fault && cb == 1) f.pval = 0;      // tests: whoever waits for this key block must give up, not hang
                 int lo0 = 0, lo1 = 0;
                 if constexpr (masked) {      // key - 32 tile - 4 h for the lane's two keys (recomputed: nothing per-lane is kept)
                     const int lane_m = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -528,7 +530,8 @@ hipError_t launch_bwd_fused_bf16(const BwdArgs& a, float* dQacc, int* ctl, int m
     if (!(a.phases & 8)) return hipSuccess;
     const size_t elems = (size_t)a.BH * a.Nq * 128;
     const int units = a.BH * (a.Nk / 256);
-    FusedArgs fa{a, dQacc, ctl};
+    const char* fault = getenv("FA2_FUSED_FAULT");
+    FusedArgs fa{a, dQacc, ctl, fault && fault[0] == '1' ? 1 : 0};
     constexpr int lds = FA2_FUSED_LDS + 16;
     if (mode == 0) {
         e = hipMemsetAsync(dQacc, 0, elems * 4, stream);

@@ -224,6 +224,32 @@ def test_any_number_of_resident_workgroups(causal, monkeypatch):
             assert torch.equal(a, b), wgs
 
 
+def test_a_lost_progress_word_ends_in_nans_not_in_a_hang(monkeypatch):
+    """Fault injection (FA2_FUSED_FAULT=1): key block 1 of every head never publishes its progress.  Key block 2 waits for
+    it with a BOUNDED poll (2^22 loads), gives up, raises the error word -- which ends everybody else's waiting -- and the
+    output pass poisons dQ: the call returns within seconds and the fault is visible.  Without the injection the same
+    call is clean again (the control block is reset by every launch)."""
+    import time
+    fa = _fa()
+    B, H, N, d = 1, 2, 1024, 128                      # four key blocks per head: blocks 2 and 3 depend on block 1
+    host, dev, O, L, scale = case(B, H, N, seed=23)
+    ws = torch.empty(fa._capi.lib().fa2_backward_workspace_bytes(B, H, N, d, 0), dtype=torch.uint8, device="cuda")
+    out = [torch.empty_like(dev[0]) for _ in range(3)]
+    run = lambda: fa.flash_attention_2_backward(dev[0], dev[1], dev[2], O, L, dev[3], scale, dQ=out[0], dK=out[1], dV=out[2],
+                                                workspace=ws)
+    monkeypatch.setenv("FA2_FUSED_FAULT", "1")
+    t0 = time.perf_counter()
+    run()
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 60.0
+    assert bool(torch.isnan(out[0].float()).all())                   # dQ poisoned ...
+    assert bool(torch.isfinite(out[1].float()).all()) and bool(torch.isfinite(out[2].float()).all())   # ... dK, dV never depended on it
+    monkeypatch.delenv("FA2_FUSED_FAULT")
+    run()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out[0].float()).all())
+
+
 def test_status_codes():
     lib = _fa()._capi.lib()
     x = torch.zeros(1, 1, 256, 128, dtype=torch.bfloat16, device="cuda")
