@@ -35,7 +35,12 @@ import os
 import re
 
 import gen_dkdv_body as base
-from gen_dkdv_body import Task, COST, READ_AHEAD, READ_LATEST
+from gen_dkdv_body import Task, COST
+
+# tuning switches (defaults = what is committed; tools/README.md)
+base.GAP_BUDGET = int(os.environ.get("FA2_GEN_BUDGET", str(base.GAP_BUDGET)))
+READ_AHEAD = int(os.environ.get("FA2_GEN_READ_AHEAD", str(base.READ_AHEAD)))
+READ_LATEST = int(os.environ.get("FA2_GEN_READ_LATEST", str(base.READ_LATEST)))
 
 D, KS, DT = 128, 8, 4
 ROWB = 2 * D
