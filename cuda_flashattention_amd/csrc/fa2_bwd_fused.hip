@@ -1,15 +1,17 @@
-// fa2_bwd_fused.hip -- PROTOTYPE of the single-kernel, five-product FlashAttention-2 backward for gfx950 (d = 128, bf16,
-// non-causal, seq_len a multiple of 256).  Not the default path: fa2_backward keeps the two deterministic kernels of
-// fa2_bwd_bf16.hip; this file exists to measure what the five-product form costs on this chip.
+// fa2_bwd_fused.hip -- the single-kernel, five-product FlashAttention-2 backward for gfx950: what fa2_backward runs for
+// bf16, d = 128, seq_len a multiple of 256, causal or not (everything else: the dQ and dK/dV kernels of fa2_bwd_bf16.hip).
+// Replaces the reference's flash_attention_2_backward_kernel (02_flash_attention_v2_backward/
+// flash_attention_backward_kernel.cu:47-246) for those shapes.  Design and measurements: DESIGN.md section 3.
 //
 // Work split as fa2_bwd_dkdv_kernel (a workgroup owns 256 keys, dK^T / dV^T in 256 accumulator registers per wave), plus the
 // query gradient: the packed dS pairs each wave already forms for dK go to a [key][q] tile in LDS, and every wave
 // contracts that tile over ALL 256 keys of the workgroup with K^T (transposed reads of the K image) for its own 32 of the
 // 128 columns -- dQ[q][col] -- so S and dP are formed once (80 MFMAs per 32-row sub-tile and wave instead of 64 + 48).
 // The main loop is a generated body (tools/gen_fused_body.py).  What remains is the sum of the dQ tiles over the N / 256
-// workgroups of a head.  MODE 0 adds them with fp32 atomics (memory-side on MI355X, ~1.3 TB/s chip-wide: the known
-// floor, B H (N/256) N d 4 bytes); MODE 1 passes a running sum from key block j to key block j + 1 through the L2 of the XCD
-// the head is pinned to (see fused_handoff below).
+// workgroups of a head.  The shipped form (CHAIN) passes a running sum from key block to key block, in a fixed order,
+// through the L2 of the XCD the head is worked on: deterministic.  The other form (fa2_backward_fused, mode 0) adds the
+// tiles with fp32 atomics (memory-side on MI355X, ~1.3 TB/s chip-wide: B H (N/256) N d 4 bytes = 6.7 ms at the bench
+// shape); it is kept as the measured alternative.
 #include <cstdlib>
 #include <type_traits>
 

@@ -63,7 +63,7 @@ struct BwdArgs {
 };
 
 hipError_t launch_bwd_bf16(const BwdArgs& a, hipStream_t stream);
-// PROTOTYPE: single-kernel five-product backward (fa2_bwd_fused.hip): d = 128, non-causal, dense, seq_len % 256 == 0.
+// Single-kernel five-product backward (fa2_bwd_fused.hip): d = 128, dense, square, seq_len % 256 == 0; causal with mode 1 only.
 // dQacc: [BH][N][128] fp32 scratch; ctl: bwd_fused_ctl_bytes of scratch; mode 0 = dQ by fp32 atomics, 1 = dQ handed from key
 // block to key block in a fixed order (deterministic).  hipErrorInvalidValue for shapes it does not take.
 size_t bwd_fused_ctl_bytes(int BH, int N);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates the main-loop body of the FUSED five-product backward prototype -> csrc/fa2_bwd_fused_body.inc.
+"""Generates the main-loop bodies of the single-kernel (five-product) backward -> csrc/fa2_bwd_fused_body.inc.
 
 One workgroup = 4 waves = 256 keys of one head (as in fa2_bwd_dkdv_kernel), but the query gradient is formed here too:
 per 32-row sub-tile and wave
@@ -398,8 +398,9 @@ def main():
               f"{sum(l > base.GAP_BUDGET for l in load)} of {NS} gaps over {base.GAP_BUDGET}")
         print("   load:", " ".join(str(l) for l in load))
         return
-    chunks = ["// GENERATED by tools/gen_fused_body.py -- do not edit.  Main-loop bodies of the fused five-product backward prototype:\n"
-              "// FA2_FUSED_BODY_B<ring buffer>_P<dS tile parity>, prologue FA2_FUSED_PRO.  Register and LDS maps: the generator.\n",
+    chunks = ["// GENERATED by tools/gen_fused_body.py -- do not edit.  Main-loop bodies of the single-kernel five-product backward:\n"
+              "// FA2_FUSED_{BODY,CBODY,MBODY}_B<ring buffer>_P<dS tile parity> (atomics form / chained / chained + causal mask), prologue\n"
+              "// FA2_FUSED_PRO.  Register and LDS maps: the generator.\n",
               f"#define FA2_FUSED_VF {VF}\n#define FA2_FUSED_DQT {DQT}\n#define FA2_FUSED_ROFFK {ROFFK}\n#define FA2_FUSED_DSWR {DSWR}\n"
               f"#define FA2_FUSED_DSRD {DSRD}\n#define FA2_FUSED_KT {KT}\n#define FA2_FUSED_QRING {QRING}\n#define FA2_FUSED_BUFB {BUFB}\n"
               f"#define FA2_FUSED_DSB {DSB}\n#define FA2_FUSED_DSTILE {DSTILE}\n#define FA2_FUSED_LDS {LDS_BYTES}\n"]
