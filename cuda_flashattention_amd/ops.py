@@ -134,3 +134,30 @@ def forward_step(Q, K, V, O, L, Oacc, M, softmax_scale, first, last, stream=None
                                       B, H, Nq, Nk, d, float(softmax_scale), _dtype_code(Q),
                                       1 if first else 0, 1 if last else 0, _stream_ptr(stream))
     check(st, "fa2_forward_step")
+
+
+class _Attention(torch.autograd.Function):
+    """flash_attention_2_forward / _backward as one differentiable op (device tensors in, device tensors out; the kernels
+    are the only arithmetic).  Saves Q, K, V, O and the log-sum-exp L, as the reference's backward expects them
+    (02_flash_attention_v2_backward/flash_attention_backward_kernel.cu:249-262)."""
+
+    @staticmethod
+    def forward(ctx, Q, K, V, softmax_scale, causal):
+        Q, K, V = Q.contiguous(), K.contiguous(), V.contiguous()
+        scale = float(softmax_scale) if softmax_scale is not None else 1.0 / math.sqrt(Q.shape[-1])
+        O, L = flash_attention_2_forward(Q, K, V, scale, causal=causal)
+        ctx.save_for_backward(Q, K, V, O, L)
+        ctx.scale, ctx.causal = scale, bool(causal)
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        Q, K, V, O, L = ctx.saved_tensors
+        dQ, dK, dV = flash_attention_2_backward(Q, K, V, O, L, dO.contiguous(), ctx.scale, causal=ctx.causal)
+        return dQ, dK, dV, None, None
+
+
+def attention(Q, K, V, softmax_scale=None, causal=False):
+    """softmax(scale Q K^T [causal]) V for [B, H, N, d] bf16 (d = 64 | 128) or fp32 (non-causal) device tensors, with gradients.
+    A convenience for callers that live in torch autograd; tests and bench.py call the two halves directly."""
+    return _Attention.apply(Q, K, V, softmax_scale, causal)
