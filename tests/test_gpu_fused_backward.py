@@ -224,6 +224,38 @@ def test_any_number_of_resident_workgroups(causal, monkeypatch):
             assert torch.equal(a, b), wgs
 
 
+def test_two_launches_on_two_streams_share_the_gpu():
+    """Two persistent grids in flight at once (separate workspaces, separate streams), each wanting every CU: whatever the
+    dispatcher gives each of them, both must finish and produce the bits of a launch that had the GPU to itself."""
+    fa = _fa()
+    B, H, N, d = 2, 8, 2048, 128
+    a_host, a_dev, aO, aL, scale = case(B, H, N, seed=31)
+    b_host, b_dev, bO, bL, _ = case(B, H, N, seed=41)
+    nb = fa._capi.lib().fa2_backward_workspace_bytes(B, H, N, d, 0)
+    wsa, wsb = (torch.empty(nb, dtype=torch.uint8, device="cuda") for _ in range(2))
+    alone_a = fa.flash_attention_2_backward(a_dev[0], a_dev[1], a_dev[2], aO, aL, a_dev[3], scale, workspace=wsa)
+    alone_b = fa.flash_attention_2_backward(b_dev[0], b_dev[1], b_dev[2], bO, bL, b_dev[3], scale, causal=False, workspace=wsb)
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for rep in range(4):
+        oa = [torch.empty_like(a_dev[0]) for _ in range(3)]
+        ob = [torch.empty_like(a_dev[0]) for _ in range(3)]
+        with torch.cuda.stream(sa):
+            fa.flash_attention_2_backward(a_dev[0], a_dev[1], a_dev[2], aO, aL, a_dev[3], scale, dQ=oa[0], dK=oa[1], dV=oa[2],
+                                          workspace=wsa, stream=sa)
+        with torch.cuda.stream(sb):
+            fa.flash_attention_2_backward(b_dev[0], b_dev[1], b_dev[2], bO, bL, b_dev[3], scale, dQ=ob[0], dK=ob[1], dV=ob[2],
+                                          workspace=wsb, stream=sb)
+        outs.append((oa, ob))
+    torch.cuda.synchronize()
+    for oa, ob in outs:
+        for x, y in zip(oa, alone_a):
+            assert torch.equal(x, y)
+        for x, y in zip(ob, alone_b):
+            assert torch.equal(x, y)
+
+
 def test_a_lost_progress_word_ends_in_nans_not_in_a_hang(monkeypatch):
     """Fault injection (FA2_FUSED_FAULT=1): key block 1 of every head never publishes its progress.  Key block 2 waits for
     it with a BOUNDED poll (2^22 loads), gives up, raises the error word -- which ends everybody else's waiting -- and the
