@@ -37,6 +37,9 @@ SUSTAINED_MFMA_TFLOPS = 1840.0
 # gfx950, plus WRITE_SIZE), summarised by tools/pmc_summary.py into this file; the JSON line names it.  A kernel that
 # is not in the file (the profile predates it) reports traffic null rather than a stale constant.
 PMC_TRAFFIC_FILE = os.path.join("profiles", "pmc_traffic.json")
+PEAK_FP8_TFLOPS = 5033.2    # dense fp8 MFMA (v_mfma_f32_32x32x64_f8f6f4): twice the bf16 rate
+# PMC evidence for the two side configurations (MFMA-busy, clock, VALU / LDS / wait split, FETCH / WRITE): see profiles/README.md
+SIDE_PMC_FILE = os.path.join("profiles", "r3_a_side_pmc_summary.txt")
 B, H, N, D = 4, 16, 8192, 128
 
 
@@ -47,6 +50,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ring", action="store_true")
+    ap.add_argument("--no-sustained", action="store_true")
+    ap.add_argument("--sustained-steps", type=int, default=350)     # 350 x ~6 ms > 2 s
     return ap.parse_args()
 
 
@@ -80,25 +85,31 @@ def median_ms(fn, torch, repeats=3, iters=10):
 
 
 def cpu_baseline(torch):
-    """The oracle (a port of the reference's naive CPU attention, oracle/naive_attention.c)
-    timed on this host: forward + backward share of every 2nd query row of ONE head of the
-    bench workload (4096 rows x 14 N d flops), all cores."""
+    """The reference's naive CPU attention (oracle/naive_attention.c: oracle_fwdbwd_heads_f32, the triple loops of
+    src/util/naive_attention.h:7-61 and the O(N^2 d) form of :84-161 in its own fp32 arithmetic) timed on this host the
+    way SURVEY 8d prescribes: ONE HEAD PER THREAD, nothing shared between threads (each keeps the dK / dV sums of its own
+    head in its own memory; no locks, no merging), every thread working on blocks of 16 consecutive query rows of its head.
+    A BOUNDED sample of the bench workload: the block count is chosen from a one-block calibration run so that the timed
+    run takes about 12 s."""
     import numpy as np
     import oracle
-    rng = np.random.default_rng(0)
-    Q, K, V = (rng.uniform(-0.5, 0.5, (N, D)).astype(np.float32) for _ in range(3))
-    dO = rng.uniform(-0.2, 0.2, (N, D)).astype(np.float32)
     cores = oracle.get_threads()
-    oracle.fwdbwd_rows(Q[:256], K[:256], V[:256], dO[:256], 0.0, (0, 1))   # page in / warm
-    stride = 2
+    heads = min(B * H, cores)
+    rng = np.random.default_rng(0)
+    Q, K, V = (rng.uniform(-0.5, 0.5, (heads, N, D)).astype(np.float32) for _ in range(3))
+    dO = rng.uniform(-0.2, 0.2, (heads, N, D)).astype(np.float32)
     t0 = time.perf_counter()
-    oracle.fwdbwd_rows(Q, K, V, dO, 0.0, (0, stride))
+    rows, *_ = oracle.fwdbwd_heads(Q, K, V, dO, 0.0, nblk=1, threads=cores)      # calibration (also pages everything in)
+    per_block = time.perf_counter() - t0
+    nblk = max(1, min(N // oracle.RB, int(12.0 / max(per_block, 1e-3))))
+    t0 = time.perf_counter()
+    rows, *_ = oracle.fwdbwd_heads(Q, K, V, dO, 0.0, nblk=nblk, threads=cores)
     dt = time.perf_counter() - t0
-    rows = len(range(0, N, stride))
     flops = 14.0 * N * D * rows
     return {"value": flops / dt / 1e12, "unit": "TFLOP/s", "cores": cores, "kind": "port",
-            "sample": f"fwd+bwd share of {rows} of {N} query rows of 1 of {B * H} heads "
-                      f"(N={N}, d={D}, fp32, {flops / 1e9:.1f} GFLOP in {dt:.2f} s)"}
+            "gflops_per_core": round(flops / dt / 1e9 / cores, 3),
+            "sample": f"naive fp32 fwd+bwd, one head per thread: {cores} threads x {nblk} blocks of {oracle.RB} query rows "
+                      f"= {rows} of the workload's {B * H * N} rows (N={N}, d={D}; {flops / 1e9:.0f} GFLOP in {dt:.2f} s)"}
 
 
 def main():
@@ -173,9 +184,33 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- sustained: the same step for >= 2 s back to back (the kernels are power-limited: a 0.1 s window after a few dozen
+    # launches does not show what the chip holds), with the mean shader clock over the window from the device's own
+    # counters (fa2_read_clocks: s_memtime / s_memrealtime x 100 MHz)
+    sustained = None
+    if rank == 0 and not args.no_sustained:
+        lib = fa._capi.lib()
+        clk = torch.zeros(4, dtype=torch.int64, device=dev)
+        cs = torch.cuda.current_stream().cuda_stream
+        n_sus = max(args.sustained_steps, 1)
+        torch.cuda.synchronize()
+        lib.fa2_read_clocks(clk.data_ptr(), cs)
+        t0s = time.perf_counter()
+        for _ in range(n_sus):
+            step()
+        lib.fa2_read_clocks(clk.data_ptr() + 16, cs)
+        torch.cuda.synchronize()
+        dts = time.perf_counter() - t0s
+        c = clk.cpu().tolist()
+        mhz = (c[2] - c[0]) / max(c[3] - c[1], 1) * 100.0
+        sustained = {"steps": n_sus, "seconds": round(dts, 3), "ms_per_step": round(dts / n_sus * 1e3, 4),
+                     "tflops": round(14.0 * B * H * N * N * D * n_sus / dts / 1e12, 2),
+                     "mean_shader_clock_mhz": round(mhz, 1),
+                     "clock_source": "fa2_read_clocks before/after the window: d(s_memtime) / d(s_memrealtime) x 100 MHz"}
 
     flops_step = 14.0 * B * H * N * N * D
     ms_per_step = elapsed / args.steps * 1e3
@@ -211,6 +246,8 @@ def main():
         "pct_mfma_peak": round(100.0 * value / world / PEAK_BF16_TFLOPS, 2),
         "roofline": roofline,
     }
+    if sustained is not None:
+        out["sustained"] = sustained
 
     # ---- side figures SURVEY 8d asks for beside the headline (timed BEFORE the CPU baseline idles the GPU): forward only at BASELINE configs[1] (bf16)
     # and the fp8 causal forward of configs[4] (B and H unspecified there: B=1, H=16)
@@ -227,7 +264,10 @@ def main():
                     f()
                 ms = median_ms(f, torch, 3, 20)          # median of three runs of 20 launches
                 fl = 4.0 * Bx * Hx * Nx * Nx * dx * (0.5 if causal else 1.0)
-                return {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1), "timing": "median of 3 x 20 launches after 50 warm-up launches"}
+                peak = PEAK_FP8_TFLOPS if dt == torch.float8_e4m3fn else PEAK_BF16_TFLOPS
+                return {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1), "timing": "median of 3 x 20 launches after 50 warm-up launches",
+                        "roofline": {"bound": "mfma", "achieved": round(fl / ms / 1e9, 1), "peak": peak, "unit": "TFLOP/s",
+                                     "frac": round(fl / ms / 1e9 / peak, 4), "counters": SIDE_PMC_FILE}}
             extra["fwd_bf16_cfg2_(4,16,4096,64)"] = fwd_only(4, 16, 4096, 64, torch.bfloat16, False)
             extra["fwd_fp8_e4m3_causal_cfg5_(1,16,32768,128)"] = fwd_only(1, 16, 32768, 128, torch.float8_e4m3fn, True)
             # the headline shape with a causal mask (past the reference, which has none): forward + backward, 7 B H N^2 d flops

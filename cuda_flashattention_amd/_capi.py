@@ -36,6 +36,8 @@ SIGNATURES = {
     "fa2_forward_fp8": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
     "fa2_backward_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "fa2_backward": (_i, [_vp] * 9 + [_i, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp]),
+    "fa2_backward_plan": (_i, [_i, _i, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_char_p)]),
+    "fa2_backward_status": (_i, [_vp, _sz, _i, _i, _i, _i, _i, _vp]),
     "fa2_backward_phases": (_i, [_vp] * 9 + [_i, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp, _i]),
     "fa2_backward_fused_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "fa2_backward_fused": (_i, [_vp] * 9 + [_i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
@@ -45,6 +47,7 @@ SIGNATURES = {
     "fa2_forward_state_finalize": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _vp]),
     "fa2_accumulate_bf16": (_i, [_vp, _vp, _sz, _i, _vp]),
     "fa2_accumulate_bf16_2d": (_i, [_vp, _vp, _sz, _sz, _sz, _i, _vp]),
+    "fa2_read_clocks": (_i, [_vp, _vp]),
     "fa2_fill_f32": (_i, [_vp, _sz, _f, _vp]),
     "fa2_convert_f32_to_bf16": (_i, [_vp, _vp, _sz, _vp]),
     "fa2_convert_bf16_to_f32": (_i, [_vp, _vp, _sz, _vp]),

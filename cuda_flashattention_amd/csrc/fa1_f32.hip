@@ -19,13 +19,13 @@
 namespace fa2 {
 
 constexpr int kFa1Rows = 64;       // query rows per workgroup = one wave
-constexpr int kFa1Bc = 64;         // keys per staged tile
+constexpr int kFa1Bc = 64;         // most keys per staged tile (the caller's Bc, clamped to 1 .. 64: LDS is sized for this)
 
 template <int DMAX>
 __global__ void __launch_bounds__(kFa1Rows) fa1_f32_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                            const float* __restrict__ V, float* __restrict__ O,
                                                            float* __restrict__ l_out, float* __restrict__ m_out, int N, int d,
-                                                           float scale)
+                                                           float scale, int Bc)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Kt = reinterpret_cast<float*>(smem);            // [Bc][d]
@@ -43,8 +43,8 @@ __global__ void __launch_bounds__(kFa1Rows) fa1_f32_kernel(const float* __restri
     }
     float m = -FLT_MAX, l = 0.0f;                           // main.cu:22-31
 
-    for (int j0 = 0; j0 < N; j0 += kFa1Bc) {
-        const int nj = min(kFa1Bc, N - j0);
+    for (int j0 = 0; j0 < N; j0 += Bc) {                    // Tc = ceil(N / Bc) tiles of the caller's Bc keys (main.cu:36)
+        const int nj = min(Bc, N - j0);
         __syncthreads();                                    // the previous tile has been consumed
         for (int i = lane; i < nj * d; i += kFa1Rows) {
             Kt[i] = K[(size_t)j0 * d + i];
@@ -95,15 +95,16 @@ __global__ void __launch_bounds__(kFa1Rows) fa1_f32_kernel(const float* __restri
     }
 }
 
-hipError_t launch_fa1_f32(const float* Q, const float* K, const float* V, float* O, float* l, float* m, int N, int d,
+hipError_t launch_fa1_f32(const float* Q, const float* K, const float* V, float* O, float* l, float* m, int N, int d, int Bc,
                           hipStream_t stream)
 {
+    Bc = Bc < 1 ? 1 : Bc > kFa1Bc ? kFa1Bc : Bc;
     const dim3 grid((unsigned)((N + kFa1Rows - 1) / kFa1Rows));
     const size_t lds = ((size_t)2 * kFa1Bc * d + (size_t)kFa1Rows * (kFa1Bc + 1)) * sizeof(float);
     const float scale = 1.0f / sqrtf((float)d);
-    if (d <= 16) hipLaunchKernelGGL((fa1_f32_kernel<16>), grid, dim3(kFa1Rows), lds, stream, Q, K, V, O, l, m, N, d, scale);
-    else if (d <= 64) hipLaunchKernelGGL((fa1_f32_kernel<64>), grid, dim3(kFa1Rows), lds, stream, Q, K, V, O, l, m, N, d, scale);
-    else hipLaunchKernelGGL((fa1_f32_kernel<128>), grid, dim3(kFa1Rows), lds, stream, Q, K, V, O, l, m, N, d, scale);
+    if (d <= 16) hipLaunchKernelGGL((fa1_f32_kernel<16>), grid, dim3(kFa1Rows), lds, stream, Q, K, V, O, l, m, N, d, scale, Bc);
+    else if (d <= 64) hipLaunchKernelGGL((fa1_f32_kernel<64>), grid, dim3(kFa1Rows), lds, stream, Q, K, V, O, l, m, N, d, scale, Bc);
+    else hipLaunchKernelGGL((fa1_f32_kernel<128>), grid, dim3(kFa1Rows), lds, stream, Q, K, V, O, l, m, N, d, scale, Bc);
     return hipGetLastError();
 }
 

@@ -13,6 +13,7 @@
 // tiles with fp32 atomics (memory-side on MI355X, ~1.3 TB/s chip-wide: B H (N/256) N d 4 bytes = 6.7 ms at the bench
 // shape); it is kept as the measured alternative.
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "fa2_common.h"
@@ -138,15 +139,25 @@ __device__ __forceinline__ void fused_dq_zero()
 //   headmap[x][k] at 32 * 18 + x (BH + 1) + k   1 + head the k-th chain of queue x works on; -1 = nothing left; 0 = not yet known
 //   prog[head][j] behind it       query sub-tiles whose running dQ sum key block j has completely stored
 constexpr int kCtlTicket = 0, kCtlNextHead = 32 * 16, kCtlError = 32 * 17, kCtlHeadmap = 32 * 18;
-constexpr int kSpinLimit = 1 << 20;
+constexpr int kSpinLimit = FA2_FUSED_SPIN_LIMIT;      // one bound for every wait: the bodies' (generated) and the unit queue's
 
 struct FusedArgs {
     BwdArgs b;
     float* dQacc;       // fp32 [BH][N][128]: zeroed by the launcher and atomically added to (CHAIN = false);
                         // the running sums as [BH][N / 32][wave][g][lane] x 4 floats (CHAIN = true: fused_dq_out_chain_kernel)
     int* ctl;           // control block (CHAIN = true)
-    int fault;          // fault injection (FA2_FUSED_FAULT=1, tests): key block 1 of every head never publishes its progress
+    int fault;          // FA2_TEST_HOOKS builds only (tests/loopback/libfa2_mi355x_hooks.so): key block 1 of every head never
+                        // publishes its progress.  The product build has neither the switch nor the code it guards.
 };
+
+// Test hooks.  The product library has none: no environment variable or call can turn dQ into NaNs or shrink the grid.
+// tests/ link a second build of THIS file with -DFA2_TEST_HOOKS (csrc/Makefile, target `hooks`) that exports a setter.
+#ifdef FA2_TEST_HOOKS
+static int g_hook_fault = 0, g_hook_grid = 0;
+extern "C" void fa2_test_set_fused_hooks(int fault, int grid) { g_hook_fault = fault; g_hook_grid = grid; }
+#else
+constexpr int g_hook_fault = 0, g_hook_grid = 0;
+#endif
 
 __device__ __forceinline__ int fused_ctl_ints(int BH, int ncb) { return kCtlHeadmap + 16 * (BH + 1) + 9 * BH * ncb; }
 
@@ -386,7 +397,9 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
                 f.pvo = (uint32_t)prev_off; f.mso = (uint32_t)mine_off;
                 f.need = (has_prev && !err && !(FA2_FUSED_DIAG & 1)) ? t + 1 : (int)0x80000000;
                 f.pval = t < n_u ? t : n_u;
+#ifdef FA2_TEST_HOOKS
                 if (fp.fault && cb == 1) f.pval = 0;      // tests: whoever waits for this key block must give up, not hang
+#endif
                 int lo0 = 0, lo1 = 0;
                 if constexpr (masked) {      // key - 32 tile - 4 h for the lane's two keys (recomputed: nothing per-lane is kept)
                     const int lane_m = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -514,6 +527,35 @@ __global__ void __launch_bounds__(256) fa2_bwd_fused_dq_out_chain_kernel(const f
     }
 }
 
+// The ordered hand-off relies on one hardware property: a workgroup's plain stores land in the L2 of the XCC whose id it
+// reads from HW_REG_XCC_ID, and sc1 loads issued on that XCC read that L2.  That was validated on gfx950 in SPX mode (one
+// device = 8 XCCs x 32 CUs = 256 CUs); on anything else the launcher does not take the chained form (fa2_backward then runs
+// the dQ and dK/dV kernels and fa2_backward_plan says why).
+bool bwd_fused_device_ok(const char** why)
+{
+    static int verdict[64] = {};          // 0 = unknown, 1 = ok, 2 = not gfx950, 3 = not 256 CUs
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { if (why) *why = "no current device"; return false; }
+    if (!verdict[dev]) {
+        hipDeviceProp_t pr;
+        if (hipGetDeviceProperties(&pr, dev) != hipSuccess) { if (why) *why = "device properties unavailable"; return false; }
+        verdict[dev] = strncmp(pr.gcnArchName, "gfx950", 6) != 0 ? 2 : pr.multiProcessorCount != 256 ? 3 : 1;
+    }
+    static const char* const text[] = {"", "single five-product kernel (gfx950, 256 CUs: the layout the ordered hand-off was validated on)",
+                                       "two kernels: device is not gfx950", "two kernels: device does not expose 256 CUs (partitioned GPU): "
+                                       "the ordered hand-off was validated in SPX mode only"};
+    if (why) *why = text[verdict[dev]];
+    return verdict[dev] == 1;
+}
+
+// the control block's error word of the last chained launch that used `ctl` (host copy; the caller has synchronised)
+hipError_t bwd_fused_read_error(const int* ctl, int* err, hipStream_t stream)
+{
+    hipError_t e = hipMemcpyAsync(err, ctl + kCtlError, sizeof(int), hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(stream);
+}
+
 // (the last 8 ints per unit are only written by -DFA2_FUSED_STATS builds: tools/gpu_stats_fused.py)
 size_t bwd_fused_ctl_bytes(int BH, int N) { return (size_t)(kCtlHeadmap + 16 * (BH + 1) + 9 * BH * (N / 256)) * sizeof(int); }
 
@@ -522,6 +564,7 @@ hipError_t launch_bwd_fused_bf16(const BwdArgs& a, float* dQacc, int* ctl, int m
     if (a.d != 128 || a.Nq != a.Nk || a.Nk % 256 != 0 || a.q_hs != a.Nq || a.k_hs != a.Nk || a.q_row0 != 0)
         return hipErrorInvalidValue;
     if (a.causal && (mode != 1 || a.causal_shift != 0)) return hipErrorInvalidValue;
+    if (mode == 1 && (a.phases & 8) && !bwd_fused_device_ok(nullptr)) return hipErrorNotSupported;
     hipError_t e = hipSuccess;
     if (a.phases & 1) {
         BwdArgs d = a;
@@ -532,8 +575,7 @@ hipError_t launch_bwd_fused_bf16(const BwdArgs& a, float* dQacc, int* ctl, int m
     if (!(a.phases & 8)) return hipSuccess;
     const size_t elems = (size_t)a.BH * a.Nq * 128;
     const int units = a.BH * (a.Nk / 256);
-    const char* fault = getenv("FA2_FUSED_FAULT");
-    FusedArgs fa{a, dQacc, ctl, fault && fault[0] == '1' ? 1 : 0};
+    FusedArgs fa{a, dQacc, ctl, g_hook_fault};
     constexpr int lds = FA2_FUSED_LDS + 16;
     if (mode == 0) {
         e = hipMemsetAsync(dQacc, 0, elems * 4, stream);
@@ -556,12 +598,9 @@ hipError_t launch_bwd_fused_bf16(const BwdArgs& a, float* dQacc, int* ctl, int m
         if (e != hipSuccess) return e;
         static bool set_t[64] = {}, set_c[64] = {};
         int wgs = units < cus[dev] ? units : cus[dev];
-        // FA2_FUSED_GRID=<n>: fewer workgroups than CUs (tests: the unit queues must drain with ANY number of resident
-        // workgroups, down to one -- the claim the hand-off's deadlock freedom rests on)
-        if (const char* g = getenv("FA2_FUSED_GRID")) {
-            const int n = atoi(g);
-            if (n >= 1 && n < wgs) wgs = n;
-        }
+        // test builds: fewer workgroups than CUs (the unit queues must drain with ANY number of resident workgroups, down
+        // to one -- the claim the hand-off's deadlock freedom rests on)
+        if (g_hook_grid >= 1 && g_hook_grid < wgs) wgs = g_hook_grid;
         const dim3 grid((unsigned)wgs);
         if (a.causal) {
             e = ensure_dynamic_lds(fa2_bwd_fused_kernel<true, true>, lds, set_c);

@@ -15,18 +15,22 @@ namespace {
 
 inline int hip_status(hipError_t e) { return e == hipSuccess ? FA2_OK : FA2_ERR_HIP_BASE - (int)e; }
 
-// The kernels address one head slab through a buffer resource (32-bit byte count, 32-bit byte offsets) and
-// the backward's row-constant planes through another: a slab of N rows must stay below 2 GiB (at 4 bytes per
-// element, the widest type) and the two planes of B H N floats as well.  Larger problems get a status, not a
-// silent wrap-around.
+// The kernels address one head slab through a buffer resource (32-bit byte count, 32-bit byte offsets): a slab of N
+// rows must stay below 2 GiB (at 4 bytes per element, the widest type).  Larger problems get a status, not a silent
+// wrap-around.
 inline int check_common(int B, int H, int N, int d, float scale)
 {
     if (B <= 0 || H <= 0 || N <= 0 || d <= 0) return FA2_ERR_INVALID_SHAPE;
     if (!(scale > 0.0f)) return FA2_ERR_INVALID_SHAPE;
     if ((long long)B * H > 0x7fffffffLL / 64) return FA2_ERR_INVALID_SHAPE;
     if ((long long)N * d * 4 > 0x7fffffffLL) return FA2_ERR_INVALID_SHAPE;
-    if ((long long)B * H * N * 8 > 0x7fffffffLL) return FA2_ERR_INVALID_SHAPE;
     return FA2_OK;
+}
+
+// bf16 backward only: its two row-constant planes (B H rows floats each) sit behind ONE buffer resource.
+inline int check_bwd_planes(int B, int H, int rows)
+{
+    return (long long)B * H * rows * 8 > 0x7fffffffLL ? FA2_ERR_INVALID_SHAPE : FA2_OK;
 }
 
 inline int check_dim(int d, int dtype)
@@ -92,6 +96,7 @@ const char* fa2_status_string(int s)
     case FA2_ERR_UNSUPPORTED_DTYPE: return "unsupported dtype";
     case FA2_ERR_WORKSPACE: return "workspace missing or too small";
     case FA2_ERR_UNSUPPORTED: return "unsupported combination";
+    case FA2_ERR_HANDOFF_TIMEOUT: return "single-kernel backward: a bounded wait for the previous key block ran out (dQ is NaN)";
     default: break;
     }
     if (s <= FA2_ERR_RCCL_BASE) return "RCCL error (code = -(status) - 2000)";
@@ -208,11 +213,16 @@ int fa2_backward_phases(const void* Q, const void* K, const void* V, const void*
     if (!workspace || workspace_bytes < fa2_backward_workspace_bytes(B, H, seq_len, head_dim, dtype))
         return FA2_ERR_WORKSPACE;
     if (dtype == FA2_DTYPE_BF16) {
+        st = check_bwd_planes(B, H, seq_len);
+        if (st) return st;
         // phases: 1 = D and the row constants, 2 = dQ kernel, 4 = dK/dV kernel, 8 = the single five-product kernel + its
-        // output pass.  7 ("all of it") takes the single kernel where the shape allows (d = 128, seq_len % 256 == 0)
+        // output pass.  7 ("all of it") takes the single kernel where the shape and the device allow (d = 128,
+        // seq_len % 256 == 0, gfx950 with all 256 CUs); bit 3 does not combine with bits 1 and 2 (they are two ways of
+        // computing the same outputs).
         const bool fused_ok = bwd_fused_shape(seq_len, head_dim, dtype);
-        if ((phases & 8) && !fused_ok) return FA2_ERR_UNSUPPORTED;
-        if ((phases & 8) || (phases == 7 && fused_ok && bwd_fused_allowed())) {
+        if ((phases & 8) && (phases & 6)) return FA2_ERR_UNSUPPORTED;
+        if ((phases & 8) && (!fused_ok || !fa2::bwd_fused_device_ok(nullptr))) return FA2_ERR_UNSUPPORTED;
+        if ((phases & 8) || (phases == 7 && fused_ok && bwd_fused_allowed() && fa2::bwd_fused_device_ok(nullptr))) {
             fa2::BwdArgs a{};
             a.Q = Q; a.K = K; a.V = V; a.O = O; a.dO = dO; a.L = L; a.dQ = dQ; a.dK = dK; a.dV = dV;
             a.D = (float*)workspace; a.BH = B * H; a.Nq = seq_len; a.Nk = seq_len; a.d = head_dim;
@@ -234,6 +244,42 @@ int fa2_backward_phases(const void* Q, const void* K, const void* V, const void*
     return hip_status(fa2::launch_bwd_f32(a, (hipStream_t)stream));
 }
 
+int fa2_backward_plan(int B, int H, int seq_len, int head_dim, int dtype, int causal, const char** reason)
+{
+    (void)causal;
+    static const char* const kShape = "two kernels: the single kernel takes bf16, head_dim 128, seq_len a multiple of 256";
+    static const char* const kEnv = "two kernels: FA2_BACKWARD_PATH=two_kernel";
+    static const char* const kF32 = "fp32 path (exact f32 MFMA kernels)";
+    if (reason) *reason = "";
+    if (B <= 0 || H <= 0 || seq_len <= 0) return FA2_ERR_INVALID_SHAPE;
+    if (dtype == FA2_DTYPE_FP8_E4M3) return FA2_ERR_UNSUPPORTED_DTYPE;
+    int st = check_dim(head_dim, dtype);
+    if (st) return st;
+    if (dtype == FA2_DTYPE_F32) { if (reason) *reason = kF32; return 2; }
+    if (!bwd_fused_shape(seq_len, head_dim, dtype)) { if (reason) *reason = kShape; return 2; }
+    if (!bwd_fused_allowed()) { if (reason) *reason = kEnv; return 2; }
+    const char* why = "";
+    const bool ok = fa2::bwd_fused_device_ok(&why);
+    if (reason) *reason = why;
+    return ok ? 1 : 2;
+}
+
+int fa2_backward_status(const void* workspace, size_t workspace_bytes, int B, int H, int seq_len, int head_dim, int dtype,
+                        void* stream)
+{
+    if (!workspace) return FA2_ERR_NULL_POINTER;
+    if (B <= 0 || H <= 0 || seq_len <= 0) return FA2_ERR_INVALID_SHAPE;
+    if (!bwd_fused_shape(seq_len, head_dim, dtype)) {           // no hand-off, nothing that can time out: only drain the stream
+        return hip_status(hipStreamSynchronize((hipStream_t)stream));
+    }
+    if (workspace_bytes < fa2_backward_workspace_bytes(B, H, seq_len, head_dim, dtype)) return FA2_ERR_WORKSPACE;
+    const char* acc = (const char*)workspace + bwd_base_ws(B, H, seq_len);
+    int err = 0;
+    hipError_t e = fa2::bwd_fused_read_error((const int*)(acc + align256((size_t)B * H * seq_len * head_dim * 4)), &err, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_status(e);
+    return err ? FA2_ERR_HANDOFF_TIMEOUT : FA2_OK;
+}
+
 int fa2_backward_block(const void* Q, const void* K, const void* V, const void* O, const float* L,
                        const void* dO, void* dQ, void* dK, void* dV,
                        int B, int H, int q_len, int kv_len, int head_dim, float softmax_scale, int dtype,
@@ -247,6 +293,8 @@ int fa2_backward_block(const void* Q, const void* K, const void* V, const void* 
     if (!st) st = check_common(B, H, q_hs > 0 ? q_hs : 1, head_dim, softmax_scale);
     if (st) return st;
     if (kv_len <= 0 || q_row0 < 0 || q_hs < q_row0 + q_len || k_hs < kv_len) return FA2_ERR_INVALID_SHAPE;
+    st = check_bwd_planes(B, H, q_hs);
+    if (st) return st;
     if (dtype != FA2_DTYPE_BF16) return FA2_ERR_UNSUPPORTED_DTYPE;
     st = check_dim(head_dim, dtype);
     if (st) return st;
@@ -274,7 +322,10 @@ int fa2_backward_fused(const void* Q, const void* K, const void* V, const void* 
     if (!Q || !K || !V || !O || !L || !dO || !dQ || !dK || !dV) return FA2_ERR_NULL_POINTER;
     int st = check_common(B, H, seq_len, head_dim, softmax_scale);
     if (st) return st;
+    if (!st) st = check_bwd_planes(B, H, seq_len);
+    if (st) return st;
     if (!bwd_fused_shape(seq_len, head_dim, FA2_DTYPE_BF16) || (mode != 0 && mode != 1)) return FA2_ERR_UNSUPPORTED;
+    if (mode == 1 && !fa2::bwd_fused_device_ok(nullptr)) return FA2_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < fa2_backward_fused_workspace_bytes(B, H, seq_len, head_dim)) return FA2_ERR_WORKSPACE;
     fa2::BwdArgs a{};
     a.Q = Q; a.K = K; a.V = V; a.O = O; a.dO = dO; a.L = L; a.dQ = dQ; a.dK = dK; a.dV = dV;
@@ -356,11 +407,11 @@ int flash_attention_2_forward(const float* Q, const float* K, const float* V,
 
 int flash_attention(const float* Q, const float* K, const float* V, float* O, float* l, float* m, int N, int d, int Bc, int M)
 {
-    (void)Bc; (void)M;
+    (void)M;                 // the reference sizes nothing from M either (main.cu:22: "we set Bc directly")
     if (!Q || !K || !V || !O || !l || !m) return FA2_ERR_NULL_POINTER;
-    if (N <= 0 || d <= 0) return FA2_ERR_INVALID_SHAPE;
+    if (N <= 0 || d <= 0 || Bc <= 0) return FA2_ERR_INVALID_SHAPE;
     if (d > 128) return FA2_ERR_UNSUPPORTED_HEAD_DIM;
-    return hip_status(fa2::launch_fa1_f32(Q, K, V, O, l, m, N, d, nullptr));
+    return hip_status(fa2::launch_fa1_f32(Q, K, V, O, l, m, N, d, Bc, nullptr));
 }
 
 int flash_attention_2_backward(const float* Q, const float* K, const float* V,
@@ -387,6 +438,12 @@ int fa2_accumulate_bf16_2d(float* acc, const void* src, size_t rows, size_t cols
     if (!acc || !src) return FA2_ERR_NULL_POINTER;
     if (pitch < cols && rows > 1) return FA2_ERR_INVALID_SHAPE;
     return hip_status(fa2::launch_accumulate_bf16(acc, src, rows, cols, pitch, init, (hipStream_t)stream));
+}
+
+int fa2_read_clocks(unsigned long long* out2, void* stream)
+{
+    if (!out2) return FA2_ERR_NULL_POINTER;
+    return hip_status(fa2::launch_read_clocks(out2, (hipStream_t)stream));
 }
 
 int fa2_fill_f32(float* dst, size_t n, float value, void* stream)

@@ -68,6 +68,11 @@ hipError_t launch_bwd_bf16(const BwdArgs& a, hipStream_t stream);
 // block to key block in a fixed order (deterministic).  hipErrorInvalidValue for shapes it does not take.
 size_t bwd_fused_ctl_bytes(int BH, int N);
 hipError_t launch_bwd_fused_bf16(const BwdArgs& a, float* dQacc, int* ctl, int mode, hipStream_t stream);
+// Whether the current device has the layout the ordered hand-off (mode 1) was validated on; *why = a static sentence.
+bool bwd_fused_device_ok(const char** why);
+// Synchronises `stream` and reads the error word a chained launch leaves in its control block (non-zero: a bounded wait
+// ran out and the output pass turned dQ into NaNs).
+hipError_t bwd_fused_read_error(const int* ctl, int* err, hipStream_t stream);
 
 // fp32 family (exact f32 MFMA, any d <= 128, any N): the reference-signature drop-ins.
 struct F32Args {
@@ -106,12 +111,13 @@ inline hipError_t ensure_dynamic_lds(Kern kern, int bytes, bool (&done)[64])
 }
 
 // FlashAttention-1 restatement (fa1_f32.hip): one head, fp32, didactic baseline row.
-hipError_t launch_fa1_f32(const float* Q, const float* K, const float* V, float* O, float* l, float* m, int N, int d,
+hipError_t launch_fa1_f32(const float* Q, const float* K, const float* V, float* O, float* l, float* m, int N, int d, int Bc,
                           hipStream_t stream);
 
 // Element-wise helpers (fa2_util.hip).
 hipError_t launch_fill_f32(float* p, size_t n, float value, hipStream_t stream);
 hipError_t launch_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t stream);
 hipError_t launch_bf16_to_f32(const void* src, float* dst, size_t n, hipStream_t stream);
+hipError_t launch_read_clocks(unsigned long long* out, hipStream_t stream);
 
 }  // namespace fa2

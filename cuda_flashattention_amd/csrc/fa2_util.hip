@@ -146,4 +146,19 @@ hipError_t launch_accumulate_bf16(float* acc, const void* src, size_t rows, size
     return hipGetLastError();
 }
 
+// Two 64-bit counters into out[0..1]: s_memtime (ticks of the shader clock) and s_memrealtime (the constant 100 MHz
+// reference).  Two calls bracket a stretch of stream work; d(memtime) / d(memrealtime) x 100 MHz is the mean shader clock
+// the chip held over it (MI355X_MICROARCH.md, DVFS give-back item 6) -- what bench.py's `sustained` object reports.
+__global__ void read_clocks_kernel(unsigned long long* out)
+{
+    out[0] = __builtin_amdgcn_s_memtime();
+    out[1] = __builtin_amdgcn_s_memrealtime();
+}
+
+hipError_t launch_read_clocks(unsigned long long* out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(read_clocks_kernel, dim3(1), dim3(1), 0, stream, out);
+    return hipGetLastError();
+}
+
 }  // namespace fa2

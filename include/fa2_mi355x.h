@@ -41,6 +41,7 @@ extern "C" {
 #define FA2_ERR_UNSUPPORTED_DTYPE -4
 #define FA2_ERR_WORKSPACE         -5   /* workspace NULL or smaller than *_workspace_bytes() */
 #define FA2_ERR_UNSUPPORTED       -6   /* combination not implemented (e.g. causal ring) */
+#define FA2_ERR_HANDOFF_TIMEOUT   -7   /* fa2_backward_status: a bounded wait of the single-kernel backward ran out; dQ is NaN */
 #define FA2_ERR_HIP_BASE          -1000 /* -(1000 + hipError_t) */
 #define FA2_ERR_RCCL_BASE         -2000 /* -(2000 + ncclResult_t) */
 
@@ -73,8 +74,9 @@ int flash_attention_2_backward(const float* Q, const float* K, const float* V,
 
 /* replaces flash_attention (01_flash_attention_v1/main.cu:7-20), the FlashAttention-1 step of the reference's staircase:
  * O = softmax(Q K^T / sqrt(d)) V for one fp32 head with the running row sums l and row maxima m written beside it
- * (m + ln l is the row's log-sum-exp).  Bc and M are accepted for signature compatibility and ignored (the reference
- * uses them to size its tiles).  A didactic baseline (scalar fp32, no MFMA): the fast path is flash_attention_2_forward. */
+ * (m + ln l is the row's log-sum-exp).  Bc is the number of keys per staged K/V tile, as in the reference (whose tests sweep
+ * Bc in {1, 2, 4}, main.cu:300-345): 1 <= Bc, values above 64 are clamped to 64 (the kernel's LDS tile); M is accepted and,
+ * as in the reference's own wrapper (main.cu:22), not used.  A didactic baseline (scalar fp32, no MFMA): the fast path is flash_attention_2_forward. */
 int flash_attention(const float* Q, const float* K, const float* V, float* O, float* l, float* m,
                     int N, int d, int Bc, int M);
 
@@ -116,9 +118,26 @@ int fa2_backward(const void* Q, const void* K, const void* V, const void* O, con
                  int B, int H, int seq_len, int head_dim, float softmax_scale,
                  int dtype, int causal, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Which implementation fa2_backward runs for this problem ON THE CURRENT DEVICE: 1 = the single five-product kernel,
+ * 2 = the dQ + dK/dV kernels (or the fp32 kernels); negative = status.  *reason (may be NULL) receives a static sentence.
+ * The single kernel hands running dQ sums from workgroup to workgroup through the L2 of the XCC both run on (they read
+ * HW_REG_XCC_ID and take work from that XCC's queue); that was validated on gfx950 exposing all 256 CUs (SPX mode).  On a
+ * partitioned GPU or another architecture fa2_backward silently uses the two kernels instead -- this call says so. */
+int fa2_backward_plan(int B, int H, int seq_len, int head_dim, int dtype, int causal, const char** reason);
+
+/* Synchronises `stream` and reports how the last fa2_backward / fa2_backward_phases / fa2_backward_fused call on that
+ * workspace ended: FA2_OK, or FA2_ERR_HANDOFF_TIMEOUT when a workgroup of the single-kernel backward gave up waiting for
+ * the key block before it (every such wait is bounded, 2^22 polls).  CONTRACT: the launch itself returns FA2_OK either way
+ * (it is asynchronous); after a time-out EVERY element of dQ is NaN (the output pass poisons it) while dK and dV are
+ * complete and correct -- they never depend on the hand-off.  A caller that consumes dK / dV without looking at dQ should
+ * call this once per step (it costs a stream synchronisation and a 4-byte copy).  Shapes that run the two kernels have no
+ * hand-off: the call only synchronises. */
+int fa2_backward_status(const void* workspace, size_t workspace_bytes, int B, int H, int seq_len, int head_dim, int dtype,
+                        void* stream);
+
 /* The same, restricted to some of its kernels -- bit 0: D = rowsum(dO o O) and the row constants into the
  * workspace, bit 1: the dQ kernel, bit 2: the dK/dV kernel, bit 3: the single five-product kernel and its output
- * pass (FA2_ERR_UNSUPPORTED for shapes it does not take).  7 = fa2_backward (which picks the implementation);
+ * pass (FA2_ERR_UNSUPPORTED for shapes or devices it does not take, and in combination with bits 1 or 2).  7 = fa2_backward (which picks the implementation);
  * 6 = the two-kernel form whatever the shape.  For profiling and for callers that overlap the two independent
  * kernels on separate streams; bits 1, 2 and 3 need what bit 0 produced in the same workspace. */
 int fa2_backward_phases(const void* Q, const void* K, const void* V, const void* O, const float* L,
@@ -190,6 +209,11 @@ int fa2_accumulate_bf16(float* acc, const void* src, size_t n, int init, void* s
 /* The same over `rows` runs of `cols` contiguous elements that start `pitch` elements apart in both acc and
  * src (a row range of every head of a [B][H][N][d] tensor). */
 int fa2_accumulate_bf16_2d(float* acc, const void* src, size_t rows, size_t cols, size_t pitch, int init, void* stream);
+
+/* Measurement aid: a one-thread kernel on `stream` writes two 64-bit device counters to out2 (DEVICE memory, 16 bytes):
+ * out2[0] = shader-clock ticks (s_memtime), out2[1] = ticks of the constant 100 MHz reference (s_memrealtime).  Bracket
+ * a stretch of work with two calls: d(out2[0]) / d(out2[1]) x 100 MHz is the mean shader clock the chip held over it. */
+int fa2_read_clocks(unsigned long long* out2, void* stream);
 
 /* Element-wise helpers (grid-stride, HBM-bound). */
 int fa2_fill_f32(float* dst, size_t n, float value, void* stream);      /* init_array, cuda_helper.h:60-65 */

@@ -157,6 +157,20 @@ def attention_backward(Q, K, V, dO, scale=0.0, causal=False):
     return dQ.reshape(shp), dK.reshape(shp), dV.reshape(shp)
 
 
+def attention_backward_head(Q, K, V, dO, scale=0.0, causal=False):
+    """dQ, dK, dV of ONE head [N, d]: attention_backward's arithmetic with the query rows split over the OpenMP threads
+    (a whole head at N = 8192 .. 65536 in seconds): what the at-size GPU tests compare a head of the backward with."""
+    Q, K, V, dO = _f32(Q), _f32(K), _f32(V), _f32(dO)
+    assert Q.ndim == 2
+    N, d = Q.shape
+    dQ, dK, dV = np.empty_like(Q), np.empty_like(Q), np.empty_like(Q)
+    fn = _oracle().oracle_attention_backward_head_f64
+    fn.restype = None
+    fn(_p(Q), _p(K), _p(V), _p(dO), _p(dQ), _p(dK), _p(dV), _c_int(N), _c_int(d), _c_float(scale),
+       _c_int(1 if causal else 0))
+    return dQ, dK, dV
+
+
 # ---------------------------------------------------------------- family 3 (ring step)
 def ring_step(Q, K, V, O, L, M, scale, last):
     """Folds one K/V shard into the (O, L, M) state in place (ring_attention_kernel.cu:67-137)."""
@@ -196,6 +210,33 @@ def fwdbwd_rows(Q, K, V, dO, scale=0.0, rows=(0, 1)):
     fn(_p(Q), _p(K), _p(V), _p(dO), _p(O), _p(dQ), _p(dK), _p(dV), _c_int(N), _c_int(d),
        _c_float(scale), _c_int(row0), _c_int(stride))
     return O, dQ, dK, dV
+
+
+RB = 16      # ORACLE_RB in naive_attention.c
+
+
+def fwdbwd_heads(Q, K, V, dO, scale=0.0, nblk=1, threads=1):
+    """cpu_baseline: the naive fp32 forward + backward, ONE HEAD PER THREAD (thread t owns head t % BH of the [BH, N, d]
+    inputs and `nblk` blocks of 16 consecutive query rows spread over it; nothing shared between threads).
+    Returns (rows processed, O_rows [threads, nblk*16, d], dQ_rows, dK [threads, N, d], dV) -- 14 N d flops per row."""
+    Q, K, V, dO = _f32(Q), _f32(K), _f32(V), _f32(dO)
+    BH, N, d = Q.shape
+    nblk = max(1, min(int(nblk), N // RB))
+    O = np.empty((threads, nblk * RB, d), np.float32)
+    dQ = np.empty_like(O)
+    dK = np.empty((threads, N, d), np.float32)
+    dV = np.empty_like(dK)
+    fn = _oracle().oracle_fwdbwd_heads_f32
+    fn.restype = ctypes.c_long
+    rows = fn(_p(Q), _p(K), _p(V), _p(dO), _p(O), _p(dQ), _p(dK), _p(dV), _c_int(BH), _c_int(N), _c_int(d),
+              _c_float(scale), _c_int(nblk), _c_int(threads))
+    return int(rows), O, dQ, dK, dV
+
+
+def fwdbwd_heads_rows(N, nblk):
+    """The query rows fwdbwd_heads works on in each head (same spacing rule as the C code)."""
+    nblk = max(1, min(int(nblk), N // RB))
+    return np.concatenate([np.arange(RB) + (b * (N // RB) // nblk) * RB for b in range(nblk)])
 
 
 def get_threads():

@@ -294,6 +294,83 @@ void oracle_attention_backward_f64(const float* Q, const float* K, const float* 
     }
 }
 
+/* The same O(N^2 d) backward for ONE head slab [N][d], with the query rows split over the OpenMP threads (private
+ * double partials of dK / dV, summed slice by slice at the end -- no critical section), so that a whole head at
+ * N = 8192 .. 65536 is seconds, not minutes: what the at-size GPU parity tests compare a head of the backward with.
+ * Same arithmetic as oracle_attention_backward_f64 (tests/test_oracle_golden.py checks them against each other). */
+void oracle_attention_backward_head_f64(const float* Q, const float* K, const float* V,
+                                        const float* dO, float* dQ, float* dK, float* dV,
+                                        int N, int d, float scale, int causal)
+{
+    if (scale == 0) scale = 1.0f / sqrtf((float)d);
+    const size_t nd = (size_t)N * d;
+    int nthreads = 1;
+    double** parts = NULL;
+#pragma omp parallel
+    {
+#pragma omp single
+        {
+#ifdef _OPENMP
+            extern int omp_get_num_threads(void);
+            nthreads = omp_get_num_threads();
+#endif
+            parts = (double**)calloc((size_t)2 * nthreads, sizeof(double*));
+        }
+        int tid = 0;
+#ifdef _OPENMP
+        extern int omp_get_thread_num(void);
+        tid = omp_get_thread_num();
+#endif
+        double* p  = (double*)malloc(sizeof(double) * (size_t)(N > 0 ? N : 1));
+        double* o  = (double*)malloc(sizeof(double) * (size_t)(d > 0 ? d : 1));
+        double* dq = (double*)malloc(sizeof(double) * (size_t)(d > 0 ? d : 1));
+        double* aK = (double*)calloc(nd > 0 ? nd : 1, sizeof(double));
+        double* aV = (double*)calloc(nd > 0 ? nd : 1, sizeof(double));
+        parts[2 * tid] = aK; parts[2 * tid + 1] = aV;
+#pragma omp for schedule(dynamic, 8)
+        for (int i = 0; i < N; ++i) {
+            const int nk = causal ? i + 1 : N;
+            const float* q = Q + (size_t)i * d;
+            const float* g = dO + (size_t)i * d;
+            (void)softmax_row_f64(q, K, nk, d, (double)scale, p);
+            for (int c = 0; c < d; ++c) o[c] = 0.0;
+            for (int j = 0; j < nk; ++j) {
+                const float* vr = V + (size_t)j * d;
+                for (int c = 0; c < d; ++c) o[c] += p[j] * (double)vr[c];
+            }
+            double D = 0.0;
+            for (int c = 0; c < d; ++c) D += (double)g[c] * o[c];
+            for (int c = 0; c < d; ++c) dq[c] = 0.0;
+            for (int j = 0; j < nk; ++j) {
+                const float* vr = V + (size_t)j * d;
+                const float* kr = K + (size_t)j * d;
+                double dp = 0.0;
+                for (int c = 0; c < d; ++c) dp += (double)g[c] * (double)vr[c];
+                const double ds = p[j] * (dp - D);
+                double* ak = aK + (size_t)j * d;
+                double* av = aV + (size_t)j * d;
+                for (int c = 0; c < d; ++c) {
+                    dq[c] += ds * (double)kr[c];
+                    ak[c] += ds * (double)q[c];
+                    av[c] += p[j] * (double)g[c];
+                }
+            }
+            for (int c = 0; c < d; ++c) dQ[(size_t)i * d + c] = (float)(dq[c] * scale);
+        }
+        /* implicit barrier above: every partial is complete; each thread now sums a slice of the elements */
+#pragma omp for schedule(static)
+        for (long t = 0; t < (long)nd; ++t) {
+            double sk = 0.0, sv = 0.0;
+            for (int w = 0; w < nthreads; ++w)
+                if (parts[2 * w]) { sk += parts[2 * w][t]; sv += parts[2 * w + 1][t]; }
+            dK[t] = (float)(sk * scale);
+            dV[t] = (float)sv;
+        }
+        free(p); free(o); free(dq); free(aK); free(aV);
+    }
+    free(parts);
+}
+
 /* ------------------------------------------------------------------------- */
 /* Family 3: one ring step (resumable online softmax)                         */
 /* ------------------------------------------------------------------------- */
@@ -342,6 +419,91 @@ void oracle_ring_step(const float* Q, const float* K, const float* V,
         }
     }
     free(s);
+}
+
+/* ------------------------------------------------------------------------- */
+/* cpu_baseline: the naive forward + backward, one head per thread             */
+/* ------------------------------------------------------------------------- */
+
+/* What bench.py times beside the GPU: the reference's triple loops in its own arithmetic type (fp32,
+ * sequential sums; naive_attention.h:15-58 for the forward, the O(N^2 d) form of :84-161 for the backward), ONE HEAD
+ * PER THREAD as the survey prescribes: thread t owns head t % BH and works on `nblk` blocks of RB = 16 consecutive
+ * query rows spread evenly over that head; its dK / dV sums are its own (nothing is shared, merged or locked), so the
+ * timing is the loops' and nothing else's.  Per block: pass 1 forms the rows' probabilities (kept transposed,
+ * pT[j][RB], one cache line per key), O and D; pass 2 walks the keys once and, per key, the block's rows -- the dK / dV
+ * row of a key is touched once per block, not once per query row.  14 N d flops per query row: the row's share of the
+ * 4 N^2 d + 10 N^2 d the bench counts.  Returns the number of query rows processed (all threads together);
+ * O_rows / dQ_rows [threads][nblk*RB][d] and dK / dV [threads][N][d] are caller scratch (checked by the CPU tests). */
+#define ORACLE_RB 16
+long oracle_fwdbwd_heads_f32(const float* Q, const float* K, const float* V, const float* dO,
+                             float* O_rows, float* dQ_rows, float* dK, float* dV,
+                             int BH, int N, int d, float scale, int nblk, int threads)
+{
+    if (scale == 0) scale = 1.0f / sqrtf((float)d);
+    const size_t nd = (size_t)N * d;
+    const int blocks_in_head = N / ORACLE_RB;
+    if (nblk > blocks_in_head) nblk = blocks_in_head;
+    if (nblk < 1 || threads < 1) return 0;
+#pragma omp parallel for schedule(static, 1) num_threads(threads)
+    for (int t = 0; t < threads; ++t) {
+        const size_t slab = (size_t)(t % BH) * nd;
+        const float *Qh = Q + slab, *Kh = K + slab, *Vh = V + slab, *Gh = dO + slab;
+        float* aK = dK + (size_t)t * nd;
+        float* aV = dV + (size_t)t * nd;
+        memset(aK, 0, nd * sizeof(float)); memset(aV, 0, nd * sizeof(float));
+        float* pT = (float*)malloc(sizeof(float) * (size_t)N * ORACLE_RB);
+        float* s  = (float*)malloc(sizeof(float) * (size_t)N);
+        float D[ORACLE_RB];
+        for (int b = 0; b < nblk; ++b) {
+            const int r0 = (int)((long)b * blocks_in_head / nblk) * ORACLE_RB;
+            float* Ob = O_rows + ((size_t)t * nblk + b) * ORACLE_RB * d;
+            float* Qb = dQ_rows + ((size_t)t * nblk + b) * ORACLE_RB * d;
+            for (int r = 0; r < ORACLE_RB; ++r) {                       /* pass 1 */
+                const float* q = Qh + (size_t)(r0 + r) * d;
+                const float* g = Gh + (size_t)(r0 + r) * d;
+                float total;
+                (void)softmax_row_ref_order(q, Kh, N, d, scale, s, &total);
+                float* o = Ob + (size_t)r * d;
+                for (int c = 0; c < d; ++c) o[c] = 0.0f;
+                for (int j = 0; j < N; ++j) {
+                    const float pj = s[j] / total;
+                    pT[(size_t)j * ORACLE_RB + r] = pj;
+                    const float* vr = Vh + (size_t)j * d;
+                    for (int c = 0; c < d; ++c) o[c] += pj * vr[c];
+                }
+                float acc = 0.0f;
+                for (int c = 0; c < d; ++c) acc += g[c] * o[c];
+                D[r] = acc;
+                float* dq = Qb + (size_t)r * d;
+                for (int c = 0; c < d; ++c) dq[c] = 0.0f;
+            }
+            for (int j = 0; j < N; ++j) {                               /* pass 2 */
+                const float* kr = Kh + (size_t)j * d;
+                const float* vr = Vh + (size_t)j * d;
+                float* ak = aK + (size_t)j * d;
+                float* av = aV + (size_t)j * d;
+                for (int r = 0; r < ORACLE_RB; ++r) {
+                    const float* q = Qh + (size_t)(r0 + r) * d;
+                    const float* g = Gh + (size_t)(r0 + r) * d;
+                    float* dq = Qb + (size_t)r * d;
+                    const float pj = pT[(size_t)j * ORACLE_RB + r];
+                    float dp = 0.0f;
+                    for (int c = 0; c < d; ++c) dp += g[c] * vr[c];
+                    const float ds = pj * (dp - D[r]);
+                    for (int c = 0; c < d; ++c) {
+                        dq[c] += ds * kr[c];
+                        ak[c] += ds * q[c];
+                        av[c] += pj * g[c];
+                    }
+                }
+            }
+            for (int r = 0; r < ORACLE_RB; ++r)
+                for (int c = 0; c < d; ++c) Qb[(size_t)r * d + c] *= scale;
+        }
+        for (size_t e = 0; e < nd; ++e) aK[e] *= scale;
+        free(pT); free(s);
+    }
+    return (long)threads * nblk * ORACLE_RB;
 }
 
 /* ------------------------------------------------------------------------- */

@@ -78,3 +78,40 @@ def test_product_never_touches_oracle():
     assert hits == [], hits
     out = subprocess.run(["ldd", os.path.join(pkg, "lib", "libfa2_mi355x.so")], capture_output=True, text=True).stdout
     assert "oracle" not in out
+
+
+def test_product_library_has_no_test_hooks():
+    """Fault injection and the forced grid size exist only in tests/loopback/libfa2_mi355x_hooks.so (fa2_bwd_fused.hip built
+    -DFA2_TEST_HOOKS); the product library neither exports the setter nor reads the round-2 environment switches, and the
+    only environment variable it reads at all is FA2_BACKWARD_PATH (once, cached)."""
+    so = os.path.join(ROOT, "cuda_flashattention_amd", "lib", "libfa2_mi355x.so")
+    exported = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    assert "fa2_test_set_fused_hooks" not in exported
+    strings = subprocess.run(["strings", so], capture_output=True, text=True, check=True).stdout
+    assert "FA2_FUSED_FAULT" not in strings and "FA2_FUSED_GRID" not in strings
+    src = os.path.join(ROOT, "cuda_flashattention_amd", "csrc")
+    hits = subprocess.run(["grep", "-rn", "getenv", src, "--include=*.hip", "--include=*.cpp", "--include=*.h"],
+                          capture_output=True, text=True).stdout.strip().splitlines()
+    assert len(hits) == 1 and "FA2_BACKWARD_PATH" in hits[0], hits
+    hooks = os.path.join(ROOT, "tests", "loopback", "libfa2_mi355x_hooks.so")
+    if os.path.exists(hooks):
+        out = subprocess.run(["nm", "-D", "--defined-only", hooks], capture_output=True, text=True, check=True).stdout
+        assert "fa2_test_set_fused_hooks" in out
+
+
+def test_plan_and_status_argument_checks():
+    """fa2_backward_plan / fa2_backward_status validate before touching a device (no GPU here: only the early returns)."""
+    from cuda_flashattention_amd import _capi
+    lib = _capi.lib()
+    why = ctypes.c_char_p()
+    assert lib.fa2_backward_plan(0, 1, 256, 128, 0, 0, ctypes.byref(why)) == -2
+    assert lib.fa2_backward_plan(1, 1, 256, 128, 2, 0, ctypes.byref(why)) == -4          # fp8 has no backward
+    assert lib.fa2_backward_plan(1, 1, 256, 96, 0, 0, ctypes.byref(why)) == -3
+    assert lib.fa2_backward_plan(1, 1, 300, 128, 0, 0, ctypes.byref(why)) == 2 and b"multiple of 256" in why.value
+    assert lib.fa2_backward_plan(1, 1, 256, 64, 1, 0, ctypes.byref(why)) == 2 and b"fp32" in why.value
+    assert lib.fa2_backward_status(None, 0, 1, 1, 256, 128, 0, None) == -1
+    assert b"NaN" in lib.fa2_status_string(-7)
+    # forward-only problems are no longer limited by the backward's row-constant planes (B H N 8 bytes < 2 GiB)
+    one = ctypes.c_void_p(16)
+    assert lib.fa2_forward(one, one, one, one, one, 64, 64, 1 << 17, 64, 0.125, 7, 0, None) == -4    # passes the shape checks
+    assert lib.fa2_backward(*([one] * 9), 64, 64, 1 << 17, 64, 0.125, 0, 0, one, 1 << 40, None) == -2

@@ -163,13 +163,18 @@ def test_fa1_baseline_reference_cases(golden):
         O = torch.full((N, d), float("nan"), device="cuda")
         l = torch.empty(N, device="cuda")
         m = torch.empty(N, device="cuda")
-        st = lib.flash_attention(dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), O.data_ptr(), l.data_ptr(), m.data_ptr(),
-                                 N, d, 32, 1024)
-        assert st == 0
-        torch.cuda.synchronize()
-        assert np.abs(O.cpu().numpy() - Oref).max() < 1e-4, nm
         _, Lr = oracle.naive_forward_pass(Q, K, V, float(1.0 / np.sqrt(d)))
-        assert np.abs((m + torch.log(l)).cpu().numpy() - Lr).max() < 1e-4, nm
+        # Bc is a test dimension in the reference (its test 8 runs one case at Bc = 1, 2, 4, main.cu:342-344; the others at
+        # Bc = 2 .. 16): every case here at Bc = 1, 2, 4, 16, 32 -- the tile length changes the order of the running (l, m, O)
+        # updates, not the result -- and one value above the clamp (1000 -> 64).
+        for Bc in (1, 2, 4, 16, 32, 1000):
+            O.fill_(float("nan"))
+            st = lib.flash_attention(dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), O.data_ptr(), l.data_ptr(), m.data_ptr(),
+                                     N, d, Bc, 1024)
+            assert st == 0
+            torch.cuda.synchronize()
+            assert np.abs(O.cpu().numpy() - Oref).max() < 1e-4, (nm, Bc)
+            assert np.abs((m + torch.log(l)).cpu().numpy() - Lr).max() < 1e-4, (nm, Bc)
 
 
 def test_fa1_baseline_matches_oracle_medium():
@@ -191,3 +196,5 @@ def test_fa1_baseline_matches_oracle_medium():
         assert np.abs((m + torch.log(l)).cpu().numpy() - Lr).max() < 1e-4
     one = ctypes_void = None
     assert lib.flash_attention(None, None, None, None, None, None, 4, 4, 32, 1024) == -1
+    assert lib.flash_attention(dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), O.data_ptr(), l.data_ptr(), m.data_ptr(),
+                               77, 5, 0, 1024) == -2          # Bc = 0

@@ -44,6 +44,34 @@ def make(B, H, N, d, seed, scale=1.0):
 
 P = lambda t: ctypes.c_void_p(t.data_ptr())
 
+_hooks = None
+
+
+def hooks_lib():
+    """tests/loopback/libfa2_mi355x_hooks.so: the core library with fa2_bwd_fused.hip compiled -DFA2_TEST_HOOKS (csrc/Makefile,
+    target `hooks`).  The PRODUCT library has no fault-injection or grid switch at all (test_capi_symbols.py); this second
+    build exports fa2_test_set_fused_hooks(fault, grid) and is bound here with the product's own signature table."""
+    global _hooks
+    if _hooks is None:
+        import os
+        from cuda_flashattention_amd import _capi
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "loopback", "libfa2_mi355x_hooks.so")
+        h = ctypes.CDLL(path)
+        for name, (res, args) in _capi.SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.restype, fn.argtypes = res, args
+        h.fa2_test_set_fused_hooks.restype = None
+        h.fa2_test_set_fused_hooks.argtypes = [ctypes.c_int, ctypes.c_int]
+        _hooks = h
+    return _hooks
+
+
+def backward_via(lib, Q, K, V, O, L, dO, scale, causal, ws, out):
+    B, H, N, d = Q.shape
+    st = lib.fa2_backward(P(Q), P(K), P(V), P(O), P(L), P(dO), P(out[0]), P(out[1]), P(out[2]), B, H, N, d, scale, 0, 1 if causal else 0,
+                          P(ws), ws.numel(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert st == 0, st
+
 
 def fused(Q, K, V, O, L, dO, scale, mode, ws=None):
     lib = _fa()._capi.lib()
@@ -107,8 +135,10 @@ def test_fa2_backward_takes_the_fused_kernel_and_matches_the_two_kernel_form():
 
 def test_ordered_handoff_is_bit_reproducible_and_long_chains_work():
     """seq_len 16384 = 64 key blocks per head, twice the CUs of an XCD: workgroups take a second unit of the same head, whose
-    first sub-tiles the chain's tail is still waiting for.  Rows sampled against the oracle's row-wise backward are too slow
-    here; the two-kernel form (itself oracle-checked at this length in test_gpu_parity.py) is the reference."""
+    first sub-tiles the chain's tail is still waiting for.  Checked against the ORACLE: one whole head (dQ, dK, dV; the
+    oracle's head-parallel fp64 backward, ~0.35 TFLOP of CPU work), plus bit-reproducibility with stale workspace contents
+    and bit-equality of dK / dV with the two-kernel form."""
+    import oracle
     fa = _fa()
     B, H, N, d = 1, 2, 16384, 128
     g = torch.Generator(device="cuda").manual_seed(3)
@@ -127,7 +157,12 @@ def test_ordered_handoff_is_bit_reproducible_and_long_chains_work():
     for x, y in zip(r1, r2):
         assert torch.equal(x, y)
     assert torch.equal(r1[1], two[1]) and torch.equal(r1[2], two[2])
-    assert rel(f32(r1[0]), f32(two[0]).astype(np.float64)) <= 1e-3
+    h = 1
+    want = oracle.attention_backward_head(f32(Q[0, h]), f32(K[0, h]), f32(V[0, h]), f32(dO[0, h]), scale)
+    for name, got, two_k, w in zip(("dQ", "dK", "dV"), r1, two, want):
+        assert rel(f32(got[0, h]), w) <= BF16_REL, (name, rel(f32(got[0, h]), w))
+        assert rel(f32(two_k[0, h]), w) <= BF16_REL, ("two-kernel " + name, rel(f32(two_k[0, h]), w))
+        assert np.abs(f32(got[0, h]) - w).max() < 5e-3, name          # 02_backward/main.cu:292-298
 
 
 def test_bench_shape_matches_the_two_kernel_form():
@@ -158,8 +193,9 @@ def test_bench_shape_matches_the_two_kernel_form():
     (1, 2, 16384),     # 64 key blocks per head
 ])
 def test_causal_fused_backward(B, H, N):
-    """Causal, through fa2_backward: vs the oracle (rel-L2 <= 5e-3), bit-reproducible, and within bf16 rounding of the
-    two-kernel form (whose sums over the query tiles run in the opposite order: no bit equality here)."""
+    """Causal, through fa2_backward: vs the oracle (rel-L2 <= 5e-3; every head up to N = 2048, one whole head at N = 16384),
+    bit-reproducible, and within bf16 rounding of the two-kernel form (whose sums over the query tiles run in the opposite
+    order: no bit equality here)."""
     import oracle
     fa = _fa()
     d = 128
@@ -192,36 +228,45 @@ def test_causal_fused_backward(B, H, N):
         want = oracle.attention_backward(*[f32(t) for t in host], scale, causal=True)
         for name, x, w in zip(("dQ", "dK", "dV"), a, want):
             assert rel(f32(x), w) <= BF16_REL, (name, rel(f32(x), w))
+    else:                 # long chains: one whole head against the oracle's head-parallel causal backward
+        h = H - 1
+        want = oracle.attention_backward_head(*[f32(t[0, h]) for t in dev], scale, causal=True)
+        for name, x, y, w in zip(("dQ", "dK", "dV"), a, c, want):
+            assert rel(f32(x[0, h]), w) <= BF16_REL, (name, rel(f32(x[0, h]), w))
+            assert rel(f32(y[0, h]), w) <= BF16_REL, ("two-kernel " + name, rel(f32(y[0, h]), w))
 
 
 @pytest.mark.parametrize("causal", [False, True])
-def test_any_number_of_resident_workgroups(causal, monkeypatch):
+def test_any_number_of_resident_workgroups(causal):
     """The hand-off never needs co-residency: a unit only waits for units taken from its queue before it.  With the grid
-    forced down to 1, 2, 3, 5 and 11 workgroups (FA2_FUSED_GRID; 24 units here, up to three per queue in flight) the kernel
-    must finish and produce the SAME BITS as with one workgroup per CU -- a single workgroup walks every unit of every XCD's
-    queue in order, so any unit that waited for a later one would spin into its bounded-poll error (NaNs)."""
+    forced down to 1, 2, 3, 5 and 11 workgroups (test build's fa2_test_set_fused_hooks; 24 units here, up to three per queue in
+    flight) the kernel must finish and produce the SAME BITS as the product library with one workgroup per CU -- a single
+    workgroup walks every unit of every XCD's queue in order, so any unit that waited for a later one would spin into its
+    bounded-poll error (NaNs)."""
     fa = _fa()
+    hl = hooks_lib()
     B, H, N, d = 1, 3, 2048, 128
     host, dev, O, L, scale = case(B, H, N, seed=17)
     if causal:
         O, L = fa.flash_attention_2_forward(dev[0], dev[1], dev[2], scale, causal=True)
     ws = torch.empty(fa._capi.lib().fa2_backward_workspace_bytes(B, H, N, d, 0), dtype=torch.uint8, device="cuda")
 
-    def run():
+    def run(lib):
         out = [torch.empty_like(dev[0]) for _ in range(3)]
-        fa.flash_attention_2_backward(dev[0], dev[1], dev[2], O, L, dev[3], scale, causal=causal, dQ=out[0], dK=out[1], dV=out[2],
-                                      workspace=ws)
+        backward_via(lib, dev[0], dev[1], dev[2], O, L, dev[3], scale, causal, ws, out)
         torch.cuda.synchronize()
         return out
 
-    monkeypatch.delenv("FA2_FUSED_GRID", raising=False)
-    ref = run()
+    ref = run(fa._capi.lib())
     assert all(bool(torch.isfinite(t.float()).all()) for t in ref)
-    for wgs in (1, 2, 3, 5, 11):
-        monkeypatch.setenv("FA2_FUSED_GRID", str(wgs))
-        got = run()
-        for a, b in zip(got, ref):
-            assert torch.equal(a, b), wgs
+    try:
+        for wgs in (1, 2, 3, 5, 11):
+            hl.fa2_test_set_fused_hooks(0, wgs)
+            got = run(hl)
+            for a, b in zip(got, ref):
+                assert torch.equal(a, b), wgs
+    finally:
+        hl.fa2_test_set_fused_hooks(0, 0)
 
 
 def test_two_launches_on_two_streams_share_the_gpu():
@@ -256,30 +301,65 @@ def test_two_launches_on_two_streams_share_the_gpu():
             assert torch.equal(x, y)
 
 
-def test_a_lost_progress_word_ends_in_nans_not_in_a_hang(monkeypatch):
-    """Fault injection (FA2_FUSED_FAULT=1): key block 1 of every head never publishes its progress.  Key block 2 waits for
-    it with a BOUNDED poll (2^22 loads), gives up, raises the error word -- which ends everybody else's waiting -- and the
-    output pass poisons dQ: the call returns within seconds and the fault is visible.  Without the injection the same
-    call is clean again (the control block is reset by every launch)."""
+def test_a_lost_progress_word_ends_in_nans_not_in_a_hang():
+    """Fault injection (test build only): key block 1 of every head never publishes its progress.  Key block 2 waits for it
+    with a BOUNDED poll (FA2_FUSED_SPIN_LIMIT = 2^22 loads, one constant for the generated bodies and the unit queue), gives
+    up, raises the error word -- which ends everybody else's waiting -- and the output pass poisons dQ: the call returns
+    within seconds, dQ is all NaN, dK / dV are intact, and fa2_backward_status reports FA2_ERR_HANDOFF_TIMEOUT (-7).
+    Without the injection the same call is clean again (the control block is reset by every launch)."""
     import time
     fa = _fa()
+    hl = hooks_lib()
     B, H, N, d = 1, 2, 1024, 128                      # four key blocks per head: blocks 2 and 3 depend on block 1
     host, dev, O, L, scale = case(B, H, N, seed=23)
     ws = torch.empty(fa._capi.lib().fa2_backward_workspace_bytes(B, H, N, d, 0), dtype=torch.uint8, device="cuda")
     out = [torch.empty_like(dev[0]) for _ in range(3)]
-    run = lambda: fa.flash_attention_2_backward(dev[0], dev[1], dev[2], O, L, dev[3], scale, dQ=out[0], dK=out[1], dV=out[2],
-                                                workspace=ws)
-    monkeypatch.setenv("FA2_FUSED_FAULT", "1")
-    t0 = time.perf_counter()
-    run()
-    torch.cuda.synchronize()
-    assert time.perf_counter() - t0 < 60.0
-    assert bool(torch.isnan(out[0].float()).all())                   # dQ poisoned ...
-    assert bool(torch.isfinite(out[1].float()).all()) and bool(torch.isfinite(out[2].float()).all())   # ... dK, dV never depended on it
-    monkeypatch.delenv("FA2_FUSED_FAULT")
-    run()
-    torch.cuda.synchronize()
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    status = lambda lib: lib.fa2_backward_status(P(ws), ws.numel(), B, H, N, d, 0, stream)
+    try:
+        hl.fa2_test_set_fused_hooks(1, 0)
+        t0 = time.perf_counter()
+        backward_via(hl, dev[0], dev[1], dev[2], O, L, dev[3], scale, False, ws, out)       # the launch itself returns FA2_OK
+        assert status(hl) == -7                                                              # ... the status call does not
+        assert time.perf_counter() - t0 < 60.0
+        assert bool(torch.isnan(out[0].float()).all())                   # dQ poisoned ...
+        assert bool(torch.isfinite(out[1].float()).all()) and bool(torch.isfinite(out[2].float()).all())   # ... dK, dV never depended on it
+    finally:
+        hl.fa2_test_set_fused_hooks(0, 0)
+    backward_via(hl, dev[0], dev[1], dev[2], O, L, dev[3], scale, False, ws, out)
+    assert status(hl) == 0
     assert bool(torch.isfinite(out[0].float()).all())
+    ref = [torch.empty_like(dev[0]) for _ in range(3)]
+    backward_via(fa._capi.lib(), dev[0], dev[1], dev[2], O, L, dev[3], scale, False, ws, ref)   # the product build: same bits
+    assert status(fa._capi.lib()) == 0
+    for a, b in zip(out, ref):
+        assert torch.equal(a, b)
+
+
+def test_environment_cannot_inject_faults_or_shrink_the_grid(monkeypatch):
+    """Round 2's FA2_FUSED_FAULT / FA2_FUSED_GRID environment switches are gone from the product library: setting them
+    changes nothing."""
+    fa = _fa()
+    B, H, N, d = 1, 2, 1024, 128
+    host, dev, O, L, scale = case(B, H, N, seed=29)
+    a = fa.flash_attention_2_backward(dev[0], dev[1], dev[2], O, L, dev[3], scale)
+    monkeypatch.setenv("FA2_FUSED_FAULT", "1")
+    monkeypatch.setenv("FA2_FUSED_GRID", "1")
+    b = fa.flash_attention_2_backward(dev[0], dev[1], dev[2], O, L, dev[3], scale)
+    torch.cuda.synchronize()
+    for x, y in zip(a, b):
+        assert bool(torch.isfinite(x.float()).all()) and torch.equal(x, y)
+
+
+def test_backward_plan_names_the_implementation():
+    """fa2_backward_plan: 1 = the single kernel on this device (gfx950, 256 CUs) for eligible shapes, 2 elsewhere, with a reason."""
+    lib = _fa()._capi.lib()
+    why = ctypes.c_char_p()
+    assert lib.fa2_backward_plan(4, 16, 8192, 128, 0, 0, ctypes.byref(why)) == 1 and b"single" in why.value
+    assert lib.fa2_backward_plan(4, 16, 8192, 64, 0, 0, ctypes.byref(why)) == 2 and b"two kernels" in why.value
+    assert lib.fa2_backward_plan(1, 1, 300, 128, 0, 0, ctypes.byref(why)) == 2
+    assert lib.fa2_backward_plan(1, 1, 256, 128, 1, 0, ctypes.byref(why)) == 2 and b"fp32" in why.value
+    assert lib.fa2_backward_plan(1, 1, 256, 128, 2, 0, None) < 0
 
 
 def test_status_codes():
@@ -300,3 +380,6 @@ def test_status_codes():
     st = lib.fa2_backward_phases(P(x64), P(x64), P(x64), P(x64), P(l), P(x64), P(x64), P(x64), P(x64), 1, 1, 256, 64, 0.1, 0, 0, P(ws),
                                  ws.numel(), None, 8)
     assert st != 0                                     # head_dim 64
+    for ph in (15, 8 | 2, 8 | 4):                      # bit 3 does not combine with the two-kernel bits
+        st = lib.fa2_backward_phases(P(x), P(x), P(x), P(x), P(l), P(x), P(x), P(x), P(x), 1, 1, 256, 128, 0.1, 0, 0, P(ws), ws.numel(), None, ph)
+        assert st == -6, (ph, st)

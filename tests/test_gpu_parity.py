@@ -254,15 +254,78 @@ def test_full_size_sampled_rows_and_properties():
     _, dQr, _, _ = oracle.fwdbwd_rows(f32(Q[b, h]), f32(K[b, h]), f32(V[b, h]), f32(dO[b, h]), s, rows=(7, 128))
     sel = np.arange(7, N, 128)
     assert rel(f32(dQ[b, h])[sel], dQr.astype(np.float64)) <= BF16_REL
-    # (iv) ONE WHOLE HEAD of the backward at this size against the oracle (about 110 GFLOP of CPU work): dK and dV
-    # need every query row, so this is what exercises the dK/dV kernel's full 128-tile sweep, its tile padding and
-    # its row-constant DMA offsets at the very shape the headline is quoted on.  Gate: 02_backward/main.cu:292-298
-    # (max |d| < 5e-3) and the bf16 rel-L2 gate.
+    # (iv) ONE WHOLE HEAD of the backward at this size against the oracle (about 110 GFLOP of CPU work, the oracle's
+    # head-parallel fp64 form): dK and dV need every query row, so this is what exercises the full 128-tile sweep, the tile
+    # padding and the row-constant DMA offsets at the very shape the headline is quoted on -- for BOTH implementations:
+    # what fa2_backward runs here (the single five-product kernel) and the two-kernel form (phases 1 + 6: the engine of
+    # every shape the single kernel does not take).  Gate: 02_backward/main.cu:292-298 (max |d| < 5e-3) and the bf16 rel-L2 gate.
+    ws = torch.empty(fa._capi.lib().fa2_backward_workspace_bytes(B, H, N, d, 0), dtype=torch.uint8, device="cuda")
+    two = [torch.empty_like(Q) for _ in range(3)]
+    for ph in (1, 6):
+        fa.flash_attention_2_backward(Q, K, V, O, L, dO, s, dQ=two[0], dK=two[1], dV=two[2], workspace=ws, phases=ph)
+    torch.cuda.synchronize()
     for (b, h) in ((3, 9),):
-        ref = oracle.attention_backward(f32(Q[b, h]), f32(K[b, h]), f32(V[b, h]), f32(dO[b, h]), s)
-        for name, got, want in zip(("dQ", "dK", "dV"), (dQ, dK, dV), ref):
+        ref = oracle.attention_backward_head(f32(Q[b, h]), f32(K[b, h]), f32(V[b, h]), f32(dO[b, h]), s)
+        for name, got, got2, want in zip(("dQ", "dK", "dV"), (dQ, dK, dV), two, ref):
             assert rel(f32(got[b, h]), want) <= BF16_REL, name
             assert np.abs(f32(got[b, h]) - want).max() < 5e-3, name
+            assert rel(f32(got2[b, h]), want) <= BF16_REL, "two-kernel " + name
+            assert np.abs(f32(got2[b, h]) - want).max() < 5e-3, "two-kernel " + name
+
+
+def test_causal_backward_at_the_bench_shape_whole_head_vs_oracle():
+    """(4,16,8192,128) CAUSAL -- the step bench.py's causal side figure times: forward rows sampled, then one whole head of
+    dQ, dK, dV of BOTH backward implementations (fa2_backward = the single kernel's causal form: reversed sub-tile order,
+    sums handed down to key block 0, masked bodies on the diagonal; and phases 1 + 6) against the oracle's causal backward.
+    Causal masking has no counterpart in the reference: parity is pinned by the oracle's masked-dense check
+    (tests/test_oracle_golden.py::test_causal_oracle_matches_masked_dense)."""
+    fa, oracle = _fa(), _oracle()
+    B, H, N, d = 4, 16, 8192, 128
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(123)
+    mk = lambda sc: ((torch.rand(B, H, N, d, device=dev, generator=g) - 0.5) * sc).bfloat16()
+    Q, K, V, dO = mk(1.0), mk(1.0), mk(1.0), mk(0.4)
+    s = 1.0 / d ** 0.5
+    O, L = fa.flash_attention_2_forward(Q, K, V, s, causal=True)
+    ws = torch.empty(fa._capi.lib().fa2_backward_workspace_bytes(B, H, N, d, 0), dtype=torch.uint8, device="cuda")
+    one = fa.flash_attention_2_backward(Q, K, V, O, L, dO, s, causal=True, workspace=ws)
+    two = [torch.empty_like(Q) for _ in range(3)]
+    for ph in (1, 6):
+        fa.flash_attention_2_backward(Q, K, V, O, L, dO, s, causal=True, dQ=two[0], dK=two[1], dV=two[2], workspace=ws, phases=ph)
+    torch.cuda.synchronize()
+    b, h = 1, 11
+    q, k, v, go = f32(Q[b, h]), f32(K[b, h]), f32(V[b, h]), f32(dO[b, h])
+    Or, Lr = oracle.attention_forward(q, k, v, s, causal=True, rows=(5, 61))
+    sel = np.arange(5, N, 61)
+    assert rel(f32(O[b, h])[sel], Or[sel]) <= BF16_REL
+    assert np.abs(L[b, h].cpu().numpy()[sel] - Lr[sel]).max() <= 1e-4
+    ref = oracle.attention_backward_head(q, k, v, go, s, causal=True)
+    for name, g1, g2, want in zip(("dQ", "dK", "dV"), one, two, ref):
+        assert rel(f32(g1[b, h]), want) <= BF16_REL, (name, rel(f32(g1[b, h]), want))
+        assert rel(f32(g2[b, h]), want) <= BF16_REL, ("two-kernel " + name, rel(f32(g2[b, h]), want))
+        assert np.abs(f32(g1[b, h]) - want).max() < 5e-3, name
+
+
+@pytest.mark.parametrize("B,H,N,causal", [(1, 2, 2048, False), (1, 2, 2048, True)])
+def test_two_kernel_backward_d128_vs_oracle(B, H, N, causal):
+    """The dQ and dK/dV kernels at d = 128 on a shape fa2_backward would give to the single kernel (phases 1 + 6 selects
+    them): every head against the oracle.  They are the ring backward's engine and the fallback on a partitioned GPU."""
+    fa, oracle = _fa(), _oracle()
+    d = 128
+    host = [make(B, H, N, d, 3 * N + i + (50 if causal else 0), 0.4 if i == 3 else 1.0) for i in range(4)]
+    devt = [t.cuda() for t in host]
+    s = 1.0 / d ** 0.5
+    O, L = fa.flash_attention_2_forward(devt[0], devt[1], devt[2], s, causal=causal)
+    ws = torch.empty(fa._capi.lib().fa2_backward_workspace_bytes(B, H, N, d, 0), dtype=torch.uint8, device="cuda")
+    out = [torch.empty_like(devt[0]) for _ in range(3)]
+    for ph in (1, 6):
+        fa.flash_attention_2_backward(devt[0], devt[1], devt[2], O, L, devt[3], s, causal=causal, dQ=out[0], dK=out[1], dV=out[2],
+                                      workspace=ws, phases=ph)
+    torch.cuda.synchronize()
+    want = oracle.attention_backward(*[f32(t) for t in host], s, causal=causal)
+    for name, got, w in zip(("dQ", "dK", "dV"), out, want):
+        assert rel(f32(got), w) <= BF16_REL, (name, rel(f32(got), w))
+        assert np.abs(f32(got) - w).max() < 5e-3, name
 
 
 def test_forward_config2_full_size_sampled_rows():

@@ -177,3 +177,41 @@ def test_k6_fa1_literal_cases(golden):
     # closed-form spot checks of the reference outputs themselves
     assert np.allclose(g["single_element_O"], [[42.0]])
     assert np.allclose(g["uniform_3x2_O"], np.tile([[3.0, 4.0]], (3, 1)), atol=1e-6)      # uniform weights: the mean of V
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_head_parallel_backward_equals_the_slab_form(causal):
+    """oracle.attention_backward_head (query rows split over threads, private partial sums) against attention_backward
+    (one thread per slab): same arithmetic, a different summation order for dK / dV only -- equal to fp64 rounding."""
+    rng = np.random.default_rng(21)
+    N, d = 203, 24
+    Q, K, V, dO = (rng.uniform(-0.5, 0.5, (N, d)).astype(np.float32) for _ in range(4))
+    a = oracle.attention_backward(Q, K, V, dO, 0.3, causal=causal)
+    b = oracle.attention_backward_head(Q, K, V, dO, 0.3, causal=causal)
+    assert np.array_equal(a[0], b[0])                       # dQ: a row is one thread's work either way
+    for x, y in zip(a[1:], b[1:]):
+        np.testing.assert_allclose(x, y, rtol=0, atol=1e-7)
+
+
+def test_cpu_baseline_loops_match_the_reference_order_oracle():
+    """oracle.fwdbwd_heads is what bench.py times as cpu_baseline: it must BE the naive forward + backward.  O rows equal
+    naive_forward_pass bit for bit (same operation order); dQ rows and each thread's dK / dV share equal the O(N^2 d)
+    backward restricted to the thread's rows (numpy float64) to fp32 rounding."""
+    rng = np.random.default_rng(8)
+    BH, N, d, nblk, threads = 2, 96, 16, 2, 3
+    Q, K, V, dO = (rng.uniform(-0.5, 0.5, (BH, N, d)).astype(np.float32) for _ in range(4))
+    s = 0.25
+    rows, O, dQ, dK, dV = oracle.fwdbwd_heads(Q, K, V, dO, s, nblk=nblk, threads=threads)
+    sel = oracle.fwdbwd_heads_rows(N, nblk)
+    assert rows == threads * nblk * oracle.RB and len(sel) == nblk * oracle.RB
+    for t in range(threads):
+        h = t % BH
+        Oref, _ = oracle.naive_forward_pass(Q[h], K[h], V[h], s)
+        assert np.array_equal(O[t], Oref[sel])
+        q, k, v, g = (a[h].astype(np.float64) for a in (Q, K, V, dO))
+        S = q[sel] @ k.T * s
+        P = np.exp(S - S.max(1, keepdims=True)); P /= P.sum(1, keepdims=True)
+        dS = P * (g[sel] @ v.T - (g[sel] * (P @ v)).sum(1, keepdims=True))
+        np.testing.assert_allclose(dQ[t], dS @ k * s, atol=2e-6)
+        np.testing.assert_allclose(dK[t], dS.T @ q[sel] * s, atol=2e-6)
+        np.testing.assert_allclose(dV[t], P.T @ g[sel], atol=2e-6)

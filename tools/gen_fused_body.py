@@ -403,7 +403,8 @@ def main():
               "// FA2_FUSED_PRO.  Register and LDS maps: the generator.\n",
               f"#define FA2_FUSED_VF {VF}\n#define FA2_FUSED_DQT {DQT}\n#define FA2_FUSED_ROFFK {ROFFK}\n#define FA2_FUSED_DSWR {DSWR}\n"
               f"#define FA2_FUSED_DSRD {DSRD}\n#define FA2_FUSED_KT {KT}\n#define FA2_FUSED_QRING {QRING}\n#define FA2_FUSED_BUFB {BUFB}\n"
-              f"#define FA2_FUSED_DSB {DSB}\n#define FA2_FUSED_DSTILE {DSTILE}\n#define FA2_FUSED_LDS {LDS_BYTES}\n"]
+              f"#define FA2_FUSED_DSB {DSB}\n#define FA2_FUSED_DSTILE {DSTILE}\n#define FA2_FUSED_LDS {LDS_BYTES}\n"
+              f"#define FA2_FUSED_SPIN_LIMIT {SPIN_LIMIT}\n"]
     p = [l for l in resolve(pro, 2, 1) if not l.startswith("s_waitcnt vmcnt") and l != "s_barrier"]      # 'next' of (buffer 2, parity 1) = (0, 0)
     p.append("s_waitcnt lgkmcnt(0)")
     chunks.append("#define FA2_FUSED_PRO \\\n" + base.c_string(p) + "\n")
