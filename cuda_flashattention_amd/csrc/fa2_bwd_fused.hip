@@ -153,10 +153,13 @@ struct FusedArgs {
 // Test hooks.  The product library has none: no environment variable or call can turn dQ into NaNs or shrink the grid.
 // tests/ link a second build of THIS file with -DFA2_TEST_HOOKS (csrc/Makefile, target `hooks`) that exports a setter.
 #ifdef FA2_TEST_HOOKS
-static int g_hook_fault = 0, g_hook_grid = 0;
+static int g_hook_fault = 0, g_hook_grid = 0, g_hook_last_grid = 0;
 extern "C" void fa2_test_set_fused_hooks(int fault, int grid) { g_hook_fault = fault; g_hook_grid = grid; }
+extern "C" int fa2_test_last_fused_grid(void) { return g_hook_last_grid; }      // workgroups of the last chained launch
+#define FA2_HOOK_NOTE_GRID(n) (g_hook_last_grid = (n))
 #else
 constexpr int g_hook_fault = 0, g_hook_grid = 0;
+#define FA2_HOOK_NOTE_GRID(n) ((void)0)
 #endif
 
 __device__ __forceinline__ int fused_ctl_ints(int BH, int ncb) { return kCtlHeadmap + 16 * (BH + 1) + 9 * BH * ncb; }
@@ -601,6 +604,7 @@ hipError_t launch_bwd_fused_bf16(const BwdArgs& a, float* dQacc, int* ctl, int m
         // test builds: fewer workgroups than CUs (the unit queues must drain with ANY number of resident workgroups, down
         // to one -- the claim the hand-off's deadlock freedom rests on)
         if (g_hook_grid >= 1 && g_hook_grid < wgs) wgs = g_hook_grid;
+        FA2_HOOK_NOTE_GRID(wgs);
         const dim3 grid((unsigned)wgs);
         if (a.causal) {
             e = ensure_dynamic_lds(fa2_bwd_fused_kernel<true, true>, lds, set_c);

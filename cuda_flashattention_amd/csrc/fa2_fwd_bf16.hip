@@ -45,7 +45,13 @@ namespace fa2 {
 
 constexpr int kFwdWaves = 8;
 constexpr int kFwdRows = 32 * kFwdWaves;   // query rows per workgroup
-constexpr int kFwdKV = 64;                  // keys per DMA tile (two 32-key half-tiles)
+// keys per DMA tile (two or four 32-key half-tile steps).  64 everywhere; -DFA2_FWD_KV64=128 builds the d = 64 kernels with
+// 128-key tiles (16 KiB per tile like d = 128).  Measured at (4,16,4096,64): no faster (866 vs 860 TFLOP/s on one box) --
+// the d = 64 forward is bound by VALU issue, not by the tile barrier -- and slower with a causal mask (coarser diagonal).
+#ifndef FA2_FWD_KV64
+#define FA2_FWD_KV64 64
+#endif
+template <int D> constexpr int fwd_kv() { return D == 64 ? FA2_FWD_KV64 : 64; }
 constexpr int kFwdBufs = 3;                 // LDS ring depth
 constexpr float kRescaleThr = 6.0f;         // natural-log units of the scaled score
 
@@ -321,12 +327,14 @@ __global__ void __launch_bounds__(64 * kFwdWaves, 1) fa2_fwd_bf16_kernel(FwdArgs
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWB = D * 2;               // bytes per tile row
+    constexpr int kFwdKV = fwd_kv<D>();       // keys per DMA tile
+    constexpr int NH = kFwdKV / 32;           // 32-key half-tile steps per tile: 2 or 4
     constexpr int TILEB = kFwdKV * ROWB;      // bytes per K (or V) tile
     constexpr int VREG = kFwdBufs * TILEB;    // LDS: [3 K tiles][3 V tiles]; every read offset < 64 KiB from its region base
     constexpr int HALFB = 32 * ROWB;          // one 32-key half-tile
     constexpr int CPR = D / 8;                // 16-byte chunks per row
     constexpr int RPI = 64 / CPR;             // rows per DMA wave-instruction (1 KiB)
-    constexpr int NP = kFwdKV / RPI;          // DMA pieces per tensor per tile: 16 or 8
+    constexpr int NP = kFwdKV / RPI;          // DMA pieces per tensor per tile (1 KiB each)
     constexpr int PPW = 2 * NP / kFwdWaves;   // DMA pieces per wave per tile: 4 or 2
     constexpr int KS = D / 16;                // k-steps of QK^T
     constexpr int DT = D / 32;                // 32-column tiles of O
@@ -564,14 +572,16 @@ __global__ void __launch_bounds__(64 * kFwdWaves, 1) fa2_fwd_bf16_kernel(FwdArgs
         scur = s0;
     }
 
-    // One 64-key tile T living in ring buffer B (= T mod 3):
-    //   step 1 (u = 2T)  : A on K[T] second half       ; X(u) ; B on V[T-1] second half (buffer B+2)
+    // One tile T (NH half-tiles of 32 keys) living in ring buffer B (= T mod 3); half-tile step u = NH T + j runs
+    // A on half-tile u + 1 and B on half-tile u - 1:
+    //   step 0           : A on K[T] half 1            ; X ; B on V[T-1] last half (buffer B+2)
     //   barrier          : buffer B+2 is free, tile T+1 has landed -> DMA tile T+2 into B+2
-    //   step 2 (u = 2T+1): A on K[T+1] first half (B+1) ; X(u) ; B on V[T] first half
+    //   steps 1 .. NH-2  : A on K[T] half j+1          ; X ; B on V[T] half j-1          (d = 64 only: NH = 4)
+    //   step NH-1        : A on K[T+1] half 0 (B+1)    ; X ; B on V[T] half NH-2
     auto tile = [&](auto B_, int T) {
         constexpr int B = decltype(B_)::value;
         constexpr int B1 = (B + 1) % kFwdBufs, B2 = (B + 2) % kFwdBufs;
-        step(std::integral_constant<int, B * TILEB + HALFB>{}, T * kFwdKV + 32, std::integral_constant<int, B2 * TILEB + HALFB>{});
+        step(std::integral_constant<int, B * TILEB + HALFB>{}, T * kFwdKV + 32, std::integral_constant<int, B2 * TILEB + (NH - 1) * HALFB>{});
 #ifdef FA2_DIAG_STAMPS
         FA2_STAMP(dg_r)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -583,7 +593,12 @@ __global__ void __launch_bounds__(64 * kFwdWaves, 1) fa2_fwd_bf16_kernel(FwdArgs
 #endif
         stage(T + 2, B2);
         FA2_STAMP(dg_sync)
-        step(std::integral_constant<int, B1 * TILEB>{}, (T + 1) * kFwdKV, std::integral_constant<int, B * TILEB>{});
+        static_for<NH - 2>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            step(std::integral_constant<int, B * TILEB + (j + 2) * HALFB>{}, T * kFwdKV + 32 * (j + 2),
+                 std::integral_constant<int, B * TILEB + j * HALFB>{});
+        });
+        step(std::integral_constant<int, B1 * TILEB>{}, (T + 1) * kFwdKV, std::integral_constant<int, B * TILEB + (NH - 2) * HALFB>{});
     };
 
 #ifdef FA2_DIAG_STAMPS
@@ -664,7 +679,7 @@ __global__ void __launch_bounds__(64 * kFwdWaves, 1) fa2_fwd_bf16_kernel(FwdArgs
 template <int D, bool CAUSAL, bool STATE>
 static hipError_t launch_one(const FwdArgs& a, hipStream_t stream)
 {
-    constexpr int lds = kFwdBufs * 2 * kFwdKV * D * 2;
+    constexpr int lds = kFwdBufs * 2 * fwd_kv<D>() * D * 2;
     auto kern = fa2_fwd_bf16_kernel<D, CAUSAL, STATE>;
     static bool attr_set[64] = {};
     hipError_t e = ensure_dynamic_lds(kern, lds, attr_set);

@@ -62,6 +62,7 @@ def hooks_lib():
             fn.restype, fn.argtypes = res, args
         h.fa2_test_set_fused_hooks.restype = None
         h.fa2_test_set_fused_hooks.argtypes = [ctypes.c_int, ctypes.c_int]
+        h.fa2_test_last_fused_grid.restype = ctypes.c_int
         _hooks = h
     return _hooks
 
@@ -263,6 +264,7 @@ def test_any_number_of_resident_workgroups(causal):
         for wgs in (1, 2, 3, 5, 11):
             hl.fa2_test_set_fused_hooks(0, wgs)
             got = run(hl)
+            assert hl.fa2_test_last_fused_grid() == wgs          # the test build's own launcher and kernels ran, at this grid
             for a, b in zip(got, ref):
                 assert torch.equal(a, b), wgs
     finally:
