@@ -189,6 +189,12 @@ size_t fa2_backward_workspace_bytes(int B, int H, int seq_len, int head_dim, int
     return bwd_base_ws(B, H, seq_len) + (bwd_fused_shape(seq_len, head_dim, dtype) ? bwd_fused_ws(B, H, seq_len, head_dim) : 0);
 }
 
+static int backward_block_impl(const void* Q, const void* K, const void* V, const void* O, const float* L,
+                               const void* dO, void* dQ, void* dK, void* dV,
+                               int B, int H, int q_len, int kv_len, int head_dim, float softmax_scale, int dtype,
+                               int q_head_stride, int kv_head_stride, int q_row0, int causal, int causal_shift,
+                               void* workspace, size_t workspace_bytes, void* stream, int phases, bool allow_single);
+
 int fa2_backward(const void* Q, const void* K, const void* V, const void* O, const float* L,
                  const void* dO, void* dQ, void* dK, void* dV,
                  int B, int H, int seq_len, int head_dim, float softmax_scale,
@@ -233,8 +239,8 @@ int fa2_backward_phases(const void* Q, const void* K, const void* V, const void*
             return hip_status(fa2::launch_bwd_fused_bf16(a, (float*)acc, (int*)(acc + align256((size_t)B * H * seq_len * head_dim * 4)), 1,
                                                          (hipStream_t)stream));
         }
-        return fa2_backward_block(Q, K, V, O, L, dO, dQ, dK, dV, B, H, seq_len, seq_len, head_dim, softmax_scale, dtype, 0, 0, 0,
-                                  causal, 0, workspace, workspace_bytes, stream, phases);
+        return backward_block_impl(Q, K, V, O, L, dO, dQ, dK, dV, B, H, seq_len, seq_len, head_dim, softmax_scale, dtype, 0, 0, 0,
+                                   causal, 0, workspace, workspace_bytes, stream, phases, false);     // phases 6 here = the two kernels
     }
     fa2::F32Args a{};
     a.Q = (const float*)Q; a.K = (const float*)K; a.V = (const float*)V; a.O = (float*)O;
@@ -280,11 +286,11 @@ int fa2_backward_status(const void* workspace, size_t workspace_bytes, int B, in
     return err ? FA2_ERR_HANDOFF_TIMEOUT : FA2_OK;
 }
 
-int fa2_backward_block(const void* Q, const void* K, const void* V, const void* O, const float* L,
+static int backward_block_impl(const void* Q, const void* K, const void* V, const void* O, const float* L,
                        const void* dO, void* dQ, void* dK, void* dV,
                        int B, int H, int q_len, int kv_len, int head_dim, float softmax_scale, int dtype,
                        int q_head_stride, int kv_head_stride, int q_row0, int causal, int causal_shift,
-                       void* workspace, size_t workspace_bytes, void* stream, int phases)
+                       void* workspace, size_t workspace_bytes, void* stream, int phases, bool allow_single)
 {
     if (!Q || !K || !V || !O || !L || !dO || !dQ || !dK || !dV) return FA2_ERR_NULL_POINTER;
     const int q_hs = q_head_stride ? q_head_stride : q_len, k_hs = kv_head_stride ? kv_head_stride : kv_len;
@@ -299,6 +305,23 @@ int fa2_backward_block(const void* Q, const void* K, const void* V, const void* 
     st = check_dim(head_dim, dtype);
     if (st) return st;
     if (!workspace || workspace_bytes < bwd_base_ws(B, H, q_hs)) return FA2_ERR_WORKSPACE;
+    // A dense square block (the ring backward's unit whenever the local length is a multiple of 256: every non-causal step,
+    // and the local causal block) IS a problem the single five-product kernel takes -- L being the log-sum-exp over more
+    // keys than the block's changes nothing for it.  Taken when both main kernels are asked for at once (phases 6 or 7),
+    // the workspace has room for its running sums and the device is the validated layout; otherwise the two kernels.
+    if (allow_single && (phases & 6) == 6 && q_len == kv_len && q_hs == q_len && k_hs == kv_len && q_row0 == 0 &&
+        (!causal || causal_shift == 0) && bwd_fused_shape(q_len, head_dim, dtype) && bwd_fused_allowed() &&
+        workspace_bytes >= fa2_backward_workspace_bytes(B, H, q_len, head_dim, dtype) && fa2::bwd_fused_device_ok(nullptr)) {
+        fa2::BwdArgs f{};
+        f.Q = Q; f.K = K; f.V = V; f.O = O; f.dO = dO; f.L = L; f.dQ = dQ; f.dK = dK; f.dV = dV;
+        f.D = (float*)workspace; f.BH = B * H; f.Nq = q_len; f.Nk = kv_len; f.d = head_dim;
+        f.RC = (float*)((char*)workspace + align256((size_t)B * H * q_hs * sizeof(float)));
+        f.q_hs = q_hs; f.k_hs = k_hs; f.q_row0 = 0; f.scale = softmax_scale; f.causal = causal ? 1 : 0; f.causal_shift = 0;
+        f.phases = 8 | (phases & 1);
+        char* acc = (char*)workspace + bwd_base_ws(B, H, q_len);
+        return hip_status(fa2::launch_bwd_fused_bf16(f, (float*)acc, (int*)(acc + align256((size_t)B * H * q_len * head_dim * 4)), 1,
+                                                     (hipStream_t)stream));
+    }
     fa2::BwdArgs a{};
     a.Q = Q; a.K = K; a.V = V; a.O = O; a.dO = dO; a.L = L; a.dQ = dQ; a.dK = dK; a.dV = dV;
     a.D = (float*)workspace; a.BH = B * H; a.Nq = q_len; a.Nk = kv_len; a.d = head_dim;
@@ -306,6 +329,16 @@ int fa2_backward_block(const void* Q, const void* K, const void* V, const void* 
     a.q_hs = q_hs; a.k_hs = k_hs; a.q_row0 = q_row0;
     a.scale = softmax_scale; a.causal = causal ? 1 : 0; a.causal_shift = causal ? causal_shift : 0; a.phases = phases & 7;
     return hip_status(fa2::launch_bwd_bf16(a, (hipStream_t)stream));
+}
+
+int fa2_backward_block(const void* Q, const void* K, const void* V, const void* O, const float* L,
+                       const void* dO, void* dQ, void* dK, void* dV,
+                       int B, int H, int q_len, int kv_len, int head_dim, float softmax_scale, int dtype,
+                       int q_head_stride, int kv_head_stride, int q_row0, int causal, int causal_shift,
+                       void* workspace, size_t workspace_bytes, void* stream, int phases)
+{
+    return backward_block_impl(Q, K, V, O, L, dO, dQ, dK, dV, B, H, q_len, kv_len, head_dim, softmax_scale, dtype, q_head_stride,
+                               kv_head_stride, q_row0, causal, causal_shift, workspace, workspace_bytes, stream, phases, true);
 }
 
 size_t fa2_backward_fused_workspace_bytes(int B, int H, int seq_len, int head_dim)

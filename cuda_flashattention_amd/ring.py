@@ -227,6 +227,16 @@ def bench_ring(dist, rank, world, steps=3, warmup=1, B=1, H=16, n_local=8192, d=
             L = torch.empty(B, H, n_local, dtype=torch.float32, device=dev)
             sec = time_it(lambda: ring_attention_forward(ctx, Q, K, V, scale, schedule=name, O_local=O, L_local=L))
             results[name] = {"ms": round(sec * 1e3, 4), "tflops": round(flops / sec / 1e12, 2)}
+        # the ring BACKWARD beside it (past the reference, whose ring is forward-only): K/V fetched from their owners, the
+        # block kernels of fa2_backward_block per resident shard (dense square blocks of this length run the single
+        # five-product kernel), dK/dV pieces exchanged while the next block runs.  10 B H N^2 d flops.
+        try:
+            dO = (torch.rand(B, H, n_local, d, device=dev, generator=g) - 0.5).mul_(0.4).to(torch.bfloat16)
+            sec = time_it(lambda: ring_attention_backward(ctx, Q, K, V, O, L, dO, scale))
+            out["backward"] = {"ms": round(sec * 1e3, 4), "tflops": round(2.5 * flops / sec / 1e12, 2),
+                               "flops": "10 B H N^2 d", "pct_mfma_peak": round(100.0 * 2.5 * flops / sec / 1e12 / world / 2516.6, 2)}
+        except Exception as e:          # a side figure of a side figure: never takes the forward's numbers down
+            out["backward"] = {"error": repr(e)}
     finally:
         ctx.close()
     out["schedules"] = results

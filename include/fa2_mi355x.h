@@ -156,7 +156,12 @@ int fa2_backward_phases(const void* Q, const void* K, const void* V, const void*
  * [B][H][q_head_stride] and the block's rows are rows [q_row0, q_row0 + q_len) of every head (the tensor
  * pointers address row q_row0 of head 0), so phase bit 0 (D = rowsum(dO o O)) may be run once over the
  * dense local tensors (q_row0 = 0, q_len = q_head_stride) and reused by every block of them.  bf16 only.
- * fa2_backward is the block q_len = kv_len = seq_len, strides 0, q_row0 0, shift 0. */
+ * fa2_backward is the block q_len = kv_len = seq_len, strides 0, q_row0 0, shift 0.
+ * phases as fa2_backward_phases bits 0..2.  With bits 1 and 2 both set (6 or 7) the library picks the implementation as
+ * fa2_backward does: a DENSE SQUARE block (q_len = kv_len, dense strides, q_row0 = 0, no shift) of head_dim 128 and a
+ * length that is a multiple of 256 runs the single five-product kernel -- provided the workspace is
+ * fa2_backward_workspace_bytes(B, H, q_len, ...) (room for its running sums) and the device is the validated layout
+ * (fa2_backward_plan) -- every other block the dQ and dK/dV kernels.  A single bit (2 or 4) always runs that kernel. */
 int fa2_backward_block(const void* Q, const void* K, const void* V, const void* O, const float* L,
                        const void* dO, void* dQ, void* dK, void* dV,
                        int B, int H, int q_len, int kv_len, int head_dim, float softmax_scale, int dtype,

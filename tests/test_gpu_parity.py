@@ -364,6 +364,8 @@ def _np_block_backward(Q, K, V, O, L, dO, scale, causal, shift):
     (64, 200, 100, 0, 200, 100, False, 0),        # more rows than keys, ragged both ways
     (128, 256, 256, 0, 256, 256, True, -64),      # causal with a NEGATIVE shift (first rows see nothing)
     (64, 130, 300, 70, 200, 300, True, 100),      # causal with a positive shift, strided rows
+    (128, 512, 512, 0, 512, 512, False, 0),       # dense square, d = 128, length % 256 == 0: the block the SINGLE five-product
+    (128, 768, 768, 0, 768, 768, True, 0),        # kernel takes (phases 7), with L shifted as if other key blocks existed
 ])
 def test_backward_block_rectangular(d, nq, nk, q_row0, q_hs, k_hs, causal, shift):
     """fa2_backward_block: q_len != kv_len, head strides, a row offset into the workspace planes and a causal shift --

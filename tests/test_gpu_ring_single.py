@@ -108,12 +108,11 @@ def test_ring_backward_one_rank_native():
     try:
         O, L = ring.ring_attention_forward(ctx, Q, K, V)
         dQ, dK, dV = ring.ring_attention_backward(ctx, Q, K, V, O, L, dO)
-        # the ring's blocks run the dQ and dK/dV kernels (fa2_backward_block); fa2_backward itself would take the
-        # single-kernel form at this shape, so its two-kernel form (phases 1, then 6) is the bit-exact reference
+        # the ring's dense square blocks go through fa2_backward_block, which -- like fa2_backward -- gives an eligible
+        # block (d = 128, local length % 256 == 0) to the single five-product kernel: fa2_backward is the bit-exact reference
         ref = [torch.empty_like(Q) for _ in range(3)]
         ws = torch.empty(fa._capi.lib().fa2_backward_workspace_bytes(B, H, N, d, 0), dtype=torch.uint8, device="cuda")
-        for ph in (1, 6):
-            fa.flash_attention_2_backward(Q, K, V, O, L, dO, dQ=ref[0], dK=ref[1], dV=ref[2], workspace=ws, phases=ph)
+        fa.flash_attention_2_backward(Q, K, V, O, L, dO, dQ=ref[0], dK=ref[1], dV=ref[2], workspace=ws)
         torch.cuda.synchronize()
         for a, b in zip((dQ, dK, dV), ref):
             assert torch.equal(a, b)              # one rank: bf16 -> fp32 -> bf16 of the same kernels' outputs

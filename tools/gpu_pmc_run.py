@@ -1,4 +1,4 @@
-"""Dev aid for rocprofv3 --pmc passes: runs each bf16 kernel twice at the bench shape -- the forward, fa2_backward as
+"""Dev aid for rocprofv3 --pmc passes: runs each bf16 kernel 12 times at the bench shape -- the forward, fa2_backward as
 shipped (delta + the single five-product kernel + its output pass) and the two-kernel form of the backward (phases 6)."""
 import sys, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +9,7 @@ Q, K, V, dO = mk(), mk(), mk(), mk()
 O = torch.empty_like(Q); L = torch.empty(B, H, N, device="cuda")
 dQ, dK, dV = torch.empty_like(Q), torch.empty_like(Q), torch.empty_like(Q)
 ws = torch.empty(fa._capi.lib().fa2_backward_workspace_bytes(B, H, N, d, 0), dtype=torch.uint8, device="cuda")
-for _ in range(2):
+for _ in range(12):
     fa.flash_attention_2_forward(Q, K, V, None, O=O, L=L)
     fa.flash_attention_2_backward(Q, K, V, O, L, dO, None, dQ=dQ, dK=dK, dV=dV, workspace=ws)
     fa.flash_attention_2_backward(Q, K, V, O, L, dO, None, dQ=dQ, dK=dK, dV=dV, workspace=ws, phases=6)
