@@ -41,6 +41,16 @@ inline int check_dim(int d, int dtype)
     return FA2_ERR_UNSUPPORTED_DTYPE;
 }
 
+// FA2_FORWARD_PATH=two_wave keeps the bf16 forward on the two-waves-per-SIMD kernel of rounds 1-2 (A/B runs, triage); read once.
+inline hipError_t launch_fwd_bf16_any(const fa2::FwdArgs& a, hipStream_t stream)
+{
+    static const bool two_wave = [] {
+        const char* e = getenv("FA2_FORWARD_PATH");
+        return e && strcmp(e, "two_wave") == 0;
+    }();
+    return two_wave ? fa2::launch_fwd_bf16(a, stream) : fa2::launch_fwd1_bf16(a, stream);
+}
+
 // Grow-only per-device scratch for the reference-signature backward, which has no workspace
 // argument (the reference cudaMemsets inside its wrapper too, :282-283).
 struct ScratchCache {
@@ -118,7 +128,7 @@ int fa2_forward(const void* Q, const void* K, const void* V, void* O, float* L,
         a.Q = Q; a.K = K; a.V = V; a.O = O; a.L = L; a.Oacc = nullptr; a.M = nullptr;
         a.BH = B * H; a.Nq = seq_len; a.Nk = seq_len; a.d = head_dim; a.scale = softmax_scale;
         a.causal = causal ? 1 : 0; a.causal_shift = 0; a.resume = 0; a.finalize = 1;
-        return hip_status(fa2::launch_fwd_bf16(a, (hipStream_t)stream));
+        return hip_status(launch_fwd_bf16_any(a, (hipStream_t)stream));
     }
     if (dtype == FA2_DTYPE_FP8_E4M3) {      // workspace from the stream-ordered allocator
         const size_t need = fa2_forward_fp8_workspace_bytes(B, H, seq_len, head_dim);
@@ -419,7 +429,7 @@ int fa2_forward_step_strided(const void* Q, const void* K, const void* V,
     a.causal = causal ? 1 : 0; a.causal_shift = causal ? causal_shift : 0;
     a.resume = first ? 0 : 1; a.finalize = last ? 1 : 0;
     a.q_hs = q_head_stride; a.k_hs = kv_head_stride;
-    return hip_status(fa2::launch_fwd_bf16(a, (hipStream_t)stream));
+    return hip_status(launch_fwd_bf16_any(a, (hipStream_t)stream));
 }
 
 int fa2_forward_state_finalize(void* O, float* L, const float* Oacc, const float* M,

@@ -1,0 +1,382 @@
+// fa2_fwd1_bf16.hip -- FlashAttention-2 forward for gfx950, bf16 in / fp32 accumulate, ONE wave per SIMD with a generated
+// main loop.  Replaces flash_attention_2_forward_kernel (reference src/02_flash_attention_v2_forward/
+// flash_attention_kernel.cu:37-297) and, through the resume / finalize switches, ring_attention_forward_kernel
+// (src/03_flash_attention_v2_ring/common/ring_attention_kernel.cu:13-140).  Same maths as fa2_fwd_bf16.hip (the two-waves-
+// per-SIMD kernel of rounds 1-2, whose stages were hand-written asm with hipcc glue between them): S^T = K Q^T so that a
+// row's max and sum are in-lane reductions, P stays in registers, lazy softmax reference, exp2 domain, natural-log L.
+//
+// What is different (round 3; tools/probes/softmax_port.hip, profiles/r3_*): the forward is co-limited by VALU issue (4 VALU
+// instructions per S element: fma, exp, add, half a max3 and half a pack) and by the MFMA pipe; with two waves per SIMD
+// hipcc-scheduled stages put 8 of the 64 VALU instructions of a 32-key step beside the 8 S^T products and 56 beside the 8 PV
+// products, and both waves of a SIMD want the VALU at the same time.  Here a workgroup is 4 waves = 256 query rows, one
+// wave per SIMD (512 registers), a wave owns 64 rows (two 32-row blocks that share every K and V^T fragment read: 0.75 LDS
+// reads per MFMA instead of 1.5), and the main loop is ONE asm body per 32-key block produced by tools/gen_fwd_body.py:
+//   A  S^T(j)  = K(j) Q^T               P  O^T += V^T(j-2) P^T(j-2)            VALU: softmax of block j-1, maxima of block j
+// -- every VALU instruction has a whole body of independent MFMAs to hide behind, every LDS read is issued 4-7 MFMAs ahead
+// of its use behind a counted lgkmcnt, the next tile's LDS-DMA is part of the body.  hipcc owns v0..v63 only
+// (amdgpu_num_vgpr(64)); v64.. and the accumulator file are named by the bodies.
+//
+// The softmax reference is lazy (as before): a body ends with "does any lane's maximum exceed its threshold", returned in
+// an SGPR; the rare update is compiler code between two bodies.  With the pipeline two blocks deep, at that point O^T holds
+// the products through block j-2, the row sums through block j-1, and P(j-1) is packed and waiting: the sums are rescaled
+// at once, O^T one body later (after P(j-1), formed at the old reference, has been added to it).
+#include <type_traits>
+
+#include "fa2_common.h"
+#include "fa2_launch.h"
+
+namespace fa2 {
+
+#include "fa2_fwd_body.inc"
+
+constexpr int kF1Waves = 4;
+constexpr int kF1Rows = 64 * kF1Waves;      // query rows per workgroup
+constexpr int kF1Bufs = 4;                  // LDS ring depth (tools/gen_fwd_body.py: NBUF)
+constexpr float kF1RescaleThr = 6.0f;       // natural-log units of the scaled score
+
+typedef __attribute__((address_space(3))) void* f1_lptr_t;
+
+template <int R>
+__device__ __forceinline__ void f1_vset(uint32_t x)
+{
+    asm volatile("v_mov_b32 v%c1, %0" : : "v"(x), "i"(R) : "v255");
+}
+template <int R>
+__device__ __forceinline__ void f1_vsetf(float x)
+{
+    asm volatile("v_mov_b32 v%c1, %0" : : "v"(x), "i"(R) : "v255");
+}
+
+#define FA2_F1_CLOBBERS "memory", "vcc", "scc", "s10", "s11", "s12", "m0", "v255", FA2_ACC_CLOBBERS
+
+struct F1Dma {
+    __amdgpu_buffer_rsrc_t krs, vrs;
+    uint32_t mw, dvo, kso;
+};
+
+// One body.  KB < NH - 1: plain; KB == NH - 1: starts with the tile barrier and issues the DMA of tile t + 2.
+template <int D, int BUF, int KB, bool MASKED>
+__device__ __forceinline__ void f1_body(float c2, const float (&mb)[2], float (&l)[2][2], float (&rm)[2], const float (&th)[2], int& need,
+                                        const int (&hi)[2], const F1Dma& dma)
+{
+#define FA2_F1_CASE(DD, B, K, M)                                                                                                  \
+    if constexpr (D == DD && BUF == B && KB == K && MASKED == bool(M))                                                              \
+        asm volatile(FA2_FWD_BODY_D##DD##_B##B##_K##K##_M##M                                                                        \
+                     : [l0a] "+v"(l[0][0]), [l0b] "+v"(l[0][1]), [l1a] "+v"(l[1][0]), [l1b] "+v"(l[1][1]), [rm0] "=&v"(rm[0]),        \
+                       [rm1] "=&v"(rm[1]), [need] "=&s"(need)                                                                       \
+                     : [c2] "s"(c2), [mb0] "v"(mb[0]), [mb1] "v"(mb[1]), [th0] "v"(th[0]), [th1] "v"(th[1]), [hi0] "v"(hi[0]),       \
+                       [hi1] "v"(hi[1]), [ninf] "v"(-INFINITY), [mw] "s"(dma.mw), [dvo] "v"(dma.dvo), [krs] "s"(dma.krs), [vrs] "s"(dma.vrs), [kso] "s"(dma.kso) \
+                     : FA2_F1_CLOBBERS);
+#define FA2_F1_CASES_B(DD, K, M) FA2_F1_CASE(DD, 0, K, M) FA2_F1_CASE(DD, 1, K, M) FA2_F1_CASE(DD, 2, K, M) FA2_F1_CASE(DD, 3, K, M)
+    FA2_F1_CASES_B(128, 0, 0) FA2_F1_CASES_B(128, 1, 0) FA2_F1_CASES_B(128, 0, 1) FA2_F1_CASES_B(128, 1, 1)
+    FA2_F1_CASES_B(64, 0, 0) FA2_F1_CASES_B(64, 1, 0) FA2_F1_CASES_B(64, 2, 0) FA2_F1_CASES_B(64, 3, 0)
+    FA2_F1_CASES_B(64, 0, 1) FA2_F1_CASES_B(64, 1, 1) FA2_F1_CASES_B(64, 2, 1) FA2_F1_CASES_B(64, 3, 1)
+#undef FA2_F1_CASES_B
+#undef FA2_F1_CASE
+}
+
+template <int D>
+__device__ __forceinline__ void f1_prologue()
+{
+    if constexpr (D == 128) asm volatile(FA2_FWD_PRO_D128 : : : FA2_F1_CLOBBERS);
+    else asm volatile(FA2_FWD_PRO_D64 : : : FA2_F1_CLOBBERS);
+}
+
+// O^T tiles of row block QB (DT x 16 accumulator registers) *= alpha (per lane = per query row)
+template <int R>
+__device__ __forceinline__ void f1_scale4(float alpha)
+{
+    float t0, t1, t2, t3;
+    asm volatile("v_accvgpr_read_b32 %0, a[%c5]\n\tv_accvgpr_read_b32 %1, a[%c6]\n\t"
+                 "v_accvgpr_read_b32 %2, a[%c7]\n\tv_accvgpr_read_b32 %3, a[%c8]\n\t"
+                 "v_mul_f32 %0, %0, %4\n\tv_mul_f32 %1, %1, %4\n\tv_mul_f32 %2, %2, %4\n\tv_mul_f32 %3, %3, %4\n\t"
+                 "v_accvgpr_write_b32 a[%c5], %0\n\tv_accvgpr_write_b32 a[%c6], %1\n\t"
+                 "v_accvgpr_write_b32 a[%c7], %2\n\tv_accvgpr_write_b32 a[%c8], %3"
+                 : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+                 : "v"(alpha), "i"(R), "i"(R + 1), "i"(R + 2), "i"(R + 3) : FA2_ACC_CLOBBERS);
+}
+
+template <int R>
+__device__ __forceinline__ void f1_acc_zero(u32x4 z)
+{
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[%c1:%c2], %0, %0, 0" : : "v"(z), "i"(R), "i"(R + 15) : FA2_ACC_CLOBBERS);
+}
+
+template <int D, bool CAUSAL, bool STATE>
+__global__ void __launch_bounds__(64 * kF1Waves, 1) __attribute__((amdgpu_num_vgpr(64))) fa2_fwd1_bf16_kernel(FwdArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ROWB = D * 2;
+    constexpr int KV = D == 128 ? FA2_FWD_D128_KV : FA2_FWD_D64_KV;      // keys per tile
+    constexpr int NH = KV / 32;                                          // key blocks (bodies) per tile
+    constexpr int TILEB = KV * ROWB;                                     // 16 KiB either way
+    constexpr int KRING = kF1Bufs * TILEB;                               // LDS: [4 K tiles][4 V tiles]
+    constexpr int CPR = D / 8;
+    constexpr int RPI = 64 / CPR;                                        // rows per 1-KiB DMA piece
+    constexpr int NP = KV / RPI;                                         // pieces per tensor per tile (16)
+    constexpr int KS = D / 16, DT = D / 32;
+    constexpr int A_O = 0, A_QF = 128;
+    constexpr int SET0 = D == 128 ? FA2_FWD_D128_SET0 : FA2_FWD_D64_SET0, SET1 = D == 128 ? FA2_FWD_D128_SET1 : FA2_FWD_D64_SET1;
+    constexpr int PF0 = D == 128 ? FA2_FWD_D128_PF0 : FA2_FWD_D64_PF0;
+    constexpr int ROFF = D == 128 ? FA2_FWD_D128_ROFF : FA2_FWD_D64_ROFF, TOFFV = D == 128 ? FA2_FWD_D128_TOFFV : FA2_FWD_D64_TOFFV;
+    static_assert(NP % kF1Waves == 0 && TILEB == 16384, "DMA piece split");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qi = lane & 31;
+    const int h = lane >> 5;
+
+    const int nrb = (p.Nq + kF1Rows - 1) / kF1Rows;
+    int head, rb;
+    map_block(blockIdx.x, p.BH, nrb, head, rb);
+    if (CAUSAL) rb = nrb - 1 - rb;            // heaviest row-blocks first
+
+    const int Nq = p.Nq, Nk = p.Nk;
+    const size_t qhs = p.q_hs ? p.q_hs : Nq, khs = p.k_hs ? p.k_hs : Nk;
+    const char* Qh = (const char*)p.Q + (size_t)head * qhs * ROWB;
+    const char* Kh = (const char*)p.K + (size_t)head * khs * ROWB;
+    const char* Vh = (const char*)p.V + (size_t)head * khs * ROWB;
+    const int q0 = rb * kF1Rows + wave * 64;              // first query row of this wave
+
+    // key blocks that hold a visible key for some row of the WORKGROUP (the tile barriers need every wave in every body);
+    // two more bodies drain the pipeline (their S^T is masked completely: P = 0)
+    int J = (Nk + 31) / 32;
+    if (CAUSAL) {
+        const int last_key = min(rb * kF1Rows + kF1Rows - 1, Nq - 1) + p.causal_shift;
+        J = min(J, last_key < 0 ? 0 : last_key / 32 + 1);
+    }
+    const int JB = J + 2;
+
+    // ---- LDS-DMA staging (per-lane source offset pre-swizzled, wave-uniform soffset, rows >= Nk read as zeros)
+    const int drow = lane / CPR, dslot = lane % CPR;
+    const int prow = wave * RPI + drow;
+    const int doff = drow * ROWB + 16 * ((lds_off<D>(prow, dslot) - ROWB * prow) >> 4);
+    const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, Nk * ROWB, 0x00020000);
+    const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, Nk * ROWB, 0x00020000);
+    auto stage = [&](int t, int buf) {
+        char* b = smem + buf * TILEB;
+#pragma unroll
+        for (int j = wave; j < 2 * NP; j += kF1Waves) {
+            const int which = j / NP, piece = j % NP;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(which ? v_rsrc : k_rsrc, (f1_lptr_t)(b + which * KRING + piece * 1024), 16, doff,
+                                                     (t * KV + piece * RPI) * ROWB, 0, 0);
+        }
+    };
+    stage(0, 0);
+    stage(1, 1);
+    stage(0, 3);          // "the tile before the first": read by the first bodies' P stage (against P = 0): must be finite
+
+    // ---- Q fragments -> AGPRs; lane holds Q[q][16 s + 8 h .. +7] of rows q0 + 32 qb + qi
+    int qrow[2];
+    static_for<2>([&](auto QB) {
+        constexpr int qb = decltype(QB)::value;
+        qrow[qb] = q0 + 32 * qb + qi;
+        const int qld = qrow[qb] < Nq ? qrow[qb] : Nq - 1;
+        static_for<KS>([&](auto S) {
+            constexpr int sidx = decltype(S)::value;
+            acc_write_frag<A_QF + (qb * KS + sidx) * 4>(*reinterpret_cast<const bf16x8*>(Qh + (size_t)qld * ROWB + 16 * (2 * sidx + h)));
+        });
+    });
+
+    // ---- running state per row block: m_run (natural units), mb = m_run log2 e (0 while -inf), thr = raw score above
+    // which the lane asks for a new reference, l = two partial row sums of the lane
+    const float inv_scale = 1.0f / p.scale;
+    float m_run[2], mb[2], thr[2], l[2][2], rm[2] = {-INFINITY, -INFINITY}, pend[2] = {1.0f, 1.0f};
+    bool have_pend = false;
+    if (STATE && p.resume) {
+        static_for<2>([&](auto QB) {
+            constexpr int qb = decltype(QB)::value;
+            const int qld = qrow[qb] < Nq ? qrow[qb] : Nq - 1;
+            const float* Oa = p.Oacc + ((size_t)head * qhs + qld) * D;
+            static_for<4 * DT>([&](auto G) {
+                constexpr int dt = decltype(G)::value / 4, g = decltype(G)::value % 4;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(Oa + 32 * dt + 8 * g + 4 * h);
+                static_for<4>([&](auto E) { acc_write<A_O + (qb * DT + dt) * 16 + 4 * g + decltype(E)::value>(v[decltype(E)::value]); });
+            });
+            m_run[qb] = p.M[(size_t)head * qhs + qld];
+            l[qb][0] = h == 0 ? p.L[(size_t)head * qhs + qld] : 0.0f;
+            l[qb][1] = 0.0f;
+            mb[qb] = m_run[qb] == -INFINITY ? 0.0f : m_run[qb] * kLog2e;
+            thr[qb] = (m_run[qb] + kF1RescaleThr) * inv_scale;
+        });
+    } else {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        static_for<2 * DT>([&](auto T) { f1_acc_zero<A_O + 16 * decltype(T)::value>(z); });
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            m_run[qb] = -INFINITY; mb[qb] = 0.0f; thr[qb] = -INFINITY; l[qb][0] = 0.0f; l[qb][1] = 0.0f;
+        }
+    }
+    // S sets and packed P of "the blocks before the first": exp2(-huge) = 0 and P = 0, so the first two bodies add exactly zero
+    static_for<32>([&](auto R) {
+        f1_vsetf<SET0 + decltype(R)::value>(-1.0e30f);
+        f1_vsetf<SET1 + decltype(R)::value>(-1.0e30f);
+        f1_vset<PF0 + decltype(R)::value>(0u);
+    });
+
+    // ---- loop-invariant LDS addresses into the registers the bodies name
+    const uint32_t lbase = (uint32_t)(uintptr_t)smem;
+    {
+        const int trq = (lane & 15) >> 2, trp = lane & 3, trcb = (lane >> 4) & 1;
+        static_for<KS>([&](auto S) {
+            constexpr int sidx = decltype(S)::value;
+            f1_vset<ROFF + sidx>(lbase + lds_off<D>(qi, 2 * sidx + h));
+        });
+        static_for<2 * DT>([&](auto I) {
+            constexpr int dt = decltype(I)::value / 2, jj = decltype(I)::value % 2;
+            f1_vset<TOFFV + decltype(I)::value>(lbase + KRING + lds_off<D>(8 * jj + 4 * h + trq, 4 * dt + 2 * trcb + (trp >> 1)) + 8 * (trp & 1));
+        });
+    }
+    const float c2 = p.scale * kLog2e;
+    F1Dma dma;
+    dma.krs = k_rsrc; dma.vrs = v_rsrc;
+    dma.mw = lbase + (uint32_t)wave * 1024u;
+    dma.dvo = (uint32_t)doff;
+    dma.kso = 0;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                         // tiles 0 and 1 have landed
+    f1_prologue<D>();
+
+    // ---- the rare path between two bodies: first the O^T rescale left over from the previous update, then a new reference
+    auto update = [&](int need) {
+        if (have_pend) {
+            asm volatile("; fa2-cold: deferred O rescale");
+            mfma_acc_settle();
+            static_for<2>([&](auto QB) {
+                constexpr int qb = decltype(QB)::value;
+                static_for<4 * DT>([&](auto R4) { f1_scale4<A_O + qb * DT * 16 + 4 * decltype(R4)::value>(pend[qb]); });
+                pend[qb] = 1.0f;
+            });
+            have_pend = false;
+        }
+        if (need) {
+            asm volatile("; fa2-cold: new softmax reference");
+            bool any_scale = false;
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                const float mx = half_max(rm[qb]) * p.scale;
+                const bool grow = mx > m_run[qb] + kF1RescaleThr;        // also true from m_run = -inf
+                const bool any_grow = __any(grow);
+                const float m_new = any_grow ? fmaxf(m_run[qb], mx) : m_run[qb];
+                // O only needs scaling if some row already accumulated something at an older reference
+                const bool sc = any_grow && __any(m_run[qb] != -INFINITY && m_new != m_run[qb]);
+                const float alpha = m_new == -INFINITY ? 1.0f : __builtin_amdgcn_exp2f((m_run[qb] - m_new) * kLog2e);
+                m_run[qb] = m_new;
+                mb[qb] = m_new == -INFINITY ? 0.0f : m_new * kLog2e;      // a row with no visible key yet keeps p = 0
+                thr[qb] = (m_new + kF1RescaleThr) * inv_scale;
+                l[qb][0] *= alpha;
+                l[qb][1] *= alpha;
+                pend[qb] = sc ? alpha : 1.0f;
+                any_scale = any_scale || sc;
+            }
+            have_pend = any_scale;
+        }
+    };
+
+    auto run_tile = [&](auto B_, int t) {
+        constexpr int B = decltype(B_)::value;
+        static_for<NH>([&](auto KB_) {
+            constexpr int kb = decltype(KB_)::value;
+            const int j = t * NH + kb;
+            if (j >= JB) return;                                  // wave- and workgroup-uniform
+            const int key0 = j * 32;
+            bool masked = key0 + 32 > Nk;
+            if (CAUSAL) masked = masked || key0 + 31 > q0 + p.causal_shift;
+            if constexpr (kb == NH - 1) dma.kso = (uint32_t)(((t + 2) * KV + wave * RPI) * ROWB);
+            int need = 0;
+            if (masked) {
+                int hi[2];
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) hi[qb] = (CAUSAL ? min(Nk, qrow[qb] + p.causal_shift + 1) : Nk) - key0 - 4 * h;
+                f1_body<D, B, kb, true>(c2, mb, l, rm, thr, need, hi, dma);
+            } else {
+                const int hi[2] = {0, 0};
+                f1_body<D, B, kb, false>(c2, mb, l, rm, thr, need, hi, dma);
+            }
+            if (need || have_pend) update(need);
+        });
+    };
+    const int ntl = (JB + NH - 1) / NH;
+    for (int t = 0; t < ntl; t += 4) {
+        run_tile(std::integral_constant<int, 0>{}, t);
+        if (t + 1 >= ntl) break;
+        run_tile(std::integral_constant<int, 1>{}, t + 1);
+        if (t + 2 >= ntl) break;
+        run_tile(std::integral_constant<int, 2>{}, t + 2);
+        if (t + 3 >= ntl) break;
+        run_tile(std::integral_constant<int, 3>{}, t + 3);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // the last bodies' look-ahead DMA and reads
+
+    // ---- epilogue
+    mfma_acc_settle();
+    const bool fin = !STATE || p.finalize;
+    static_for<2>([&](auto QB) {
+        constexpr int qb = decltype(QB)::value;
+        const float l_tot = half_sum(l[qb][0] + l[qb][1]);
+        const size_t qoff = (size_t)head * qhs + qrow[qb];
+        const float pa = pend[qb];                 // an O rescale still pending from the last update (1 otherwise)
+        const float inv = (fin ? (l_tot > 0.0f ? 1.0f / l_tot : 0.0f) : 1.0f) * pa;
+        // a lane holds 4 consecutive columns of its row per register quad, its partner lane (+32) the next 4: for the bf16
+        // output one v_permlane32_swap per packed dword pairs them up, so that every lane stores 16 contiguous bytes
+        static_for<2 * DT>([&](auto G) {
+            constexpr int dt = decltype(G)::value / 2, gp = decltype(G)::value % 2;
+            constexpr int R = A_O + (qb * DT + dt) * 16 + 8 * gp;
+            f32x4 v, w;
+            v[0] = acc_read<R>() * inv; v[1] = acc_read<R + 1>() * inv; v[2] = acc_read<R + 2>() * inv; v[3] = acc_read<R + 3>() * inv;
+            w[0] = acc_read<R + 4>() * inv; w[1] = acc_read<R + 5>() * inv; w[2] = acc_read<R + 6>() * inv; w[3] = acc_read<R + 7>() * inv;
+            if (fin) {
+                bf16x4 x, y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { x[e] = (__bf16)v[e]; y[e] = (__bf16)w[e]; }
+                const u32x2 xu = __builtin_bit_cast(u32x2, x), yu = __builtin_bit_cast(u32x2, y);
+                const auto s0 = __builtin_amdgcn_permlane32_swap(xu[0], yu[0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(xu[1], yu[1], false, false);
+                const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+                if (qrow[qb] < Nq) *reinterpret_cast<u32x4*>((char*)p.O + qoff * ROWB + 2 * (32 * dt + 16 * gp + 8 * h)) = o;
+            } else if (qrow[qb] < Nq) {
+                *reinterpret_cast<f32x4*>(p.Oacc + qoff * D + 32 * dt + 16 * gp + 4 * h) = v;
+                *reinterpret_cast<f32x4*>(p.Oacc + qoff * D + 32 * dt + 16 * gp + 8 + 4 * h) = w;
+            }
+        });
+        if (qrow[qb] < Nq && h == 0) {
+            if (fin) {
+                p.L[qoff] = m_run[qb] + __builtin_logf(l_tot);
+            } else {
+                p.L[qoff] = l_tot;
+                p.M[qoff] = m_run[qb];
+            }
+        }
+    });
+}
+
+template <int D, bool CAUSAL, bool STATE>
+static hipError_t launch_one1(const FwdArgs& a, hipStream_t stream)
+{
+    constexpr int lds = 2 * kF1Bufs * 16384;
+    auto kern = fa2_fwd1_bf16_kernel<D, CAUSAL, STATE>;
+    static bool attr_set[64] = {};
+    hipError_t e = ensure_dynamic_lds(kern, lds, attr_set);
+    if (e != hipSuccess) return e;
+    const int nrb = (a.Nq + kF1Rows - 1) / kF1Rows;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nrb * a.BH)), dim3(64 * kF1Waves), lds, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_fwd1_bf16(const FwdArgs& a, hipStream_t stream)
+{
+    const bool state = a.resume || !a.finalize;
+    if (a.d == 128) {
+        if (state) return a.causal ? launch_one1<128, true, true>(a, stream) : launch_one1<128, false, true>(a, stream);
+        return a.causal ? launch_one1<128, true, false>(a, stream) : launch_one1<128, false, false>(a, stream);
+    }
+    if (a.d == 64) {
+        if (state) return a.causal ? launch_one1<64, true, true>(a, stream) : launch_one1<64, false, true>(a, stream);
+        return a.causal ? launch_one1<64, true, false>(a, stream) : launch_one1<64, false, false>(a, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace fa2

@@ -28,7 +28,8 @@ struct FwdArgs {
                       // Larger strides address a row range of every head (the zig-zag chunks of the causal ring).
 };
 
-hipError_t launch_fwd_bf16(const FwdArgs& a, hipStream_t stream);
+hipError_t launch_fwd_bf16(const FwdArgs& a, hipStream_t stream);      // two waves per SIMD, hand-written stages (rounds 1-2)
+hipError_t launch_fwd1_bf16(const FwdArgs& a, hipStream_t stream);     // one wave per SIMD, generated main loop (round 3)
 // acc (fp32) = (init) or += src (bf16): `rows` runs of `cols` elements, `pitch` elements apart in both.
 hipError_t launch_accumulate_bf16(float* acc, const void* src, size_t rows, size_t cols, size_t pitch, int init, hipStream_t stream);
 // Ring epilogue: O = bf16(Oacc / l), L = m + ln l for `rows` consecutive rows (l arrives in L).
