@@ -55,17 +55,23 @@ struct F1Dma {
 };
 
 // One body.  KB < NH - 1: plain; KB == NH - 1: starts with the tile barrier and issues the DMA of tile t + 2.
+template <int R>
+__device__ __forceinline__ float f1_vget()
+{
+    float x;
+    asm volatile("v_mov_b32 %0, v%c1" : "=v"(x) : "i"(R));
+    return x;
+}
+
 template <int D, int BUF, int KB, bool MASKED>
-__device__ __forceinline__ void f1_body(float c2, const float (&mb)[2], float (&l)[2][2], float (&rm)[2], const float (&th)[2], int& need,
-                                        const int (&hi)[2], const F1Dma& dma)
+__device__ __forceinline__ void f1_body(float c2, int& need, const int (&hi)[2], const F1Dma& dma)
 {
 #define FA2_F1_CASE(DD, B, K, M)                                                                                                  \
     if constexpr (D == DD && BUF == B && KB == K && MASKED == bool(M))                                                              \
         asm volatile(FA2_FWD_BODY_D##DD##_B##B##_K##K##_M##M                                                                        \
-                     : [l0a] "+v"(l[0][0]), [l0b] "+v"(l[0][1]), [l1a] "+v"(l[1][0]), [l1b] "+v"(l[1][1]), [rm0] "=&v"(rm[0]),        \
-                       [rm1] "=&v"(rm[1]), [need] "=&s"(need)                                                                       \
-                     : [c2] "s"(c2), [mb0] "v"(mb[0]), [mb1] "v"(mb[1]), [th0] "v"(th[0]), [th1] "v"(th[1]), [hi0] "v"(hi[0]),       \
-                       [hi1] "v"(hi[1]), [ninf] "v"(-INFINITY), [mw] "s"(dma.mw), [dvo] "v"(dma.dvo), [krs] "s"(dma.krs), [vrs] "s"(dma.vrs), [kso] "s"(dma.kso) \
+                     : [need] "=&s"(need)                                                                                            \
+                     : [c2] "s"(c2), [hi0] "v"(hi[0]), [hi1] "v"(hi[1]), [ninf] "v"(-INFINITY), [mw] "s"(dma.mw), [dvo] "v"(dma.dvo),      \
+                       [krs] "s"(dma.krs), [vrs] "s"(dma.vrs), [kso] "s"(dma.kso)                                                     \
                      : FA2_F1_CLOBBERS);
 #define FA2_F1_CASES_B(DD, K, M) FA2_F1_CASE(DD, 0, K, M) FA2_F1_CASE(DD, 1, K, M) FA2_F1_CASE(DD, 2, K, M) FA2_F1_CASE(DD, 3, K, M)
     FA2_F1_CASES_B(128, 0, 0) FA2_F1_CASES_B(128, 1, 0) FA2_F1_CASES_B(128, 0, 1) FA2_F1_CASES_B(128, 1, 1)
@@ -119,6 +125,7 @@ __global__ void __launch_bounds__(64 * kF1Waves, 1) __attribute__((amdgpu_num_vg
     constexpr int SET0 = D == 128 ? FA2_FWD_D128_SET0 : FA2_FWD_D64_SET0, SET1 = D == 128 ? FA2_FWD_D128_SET1 : FA2_FWD_D64_SET1;
     constexpr int PF0 = D == 128 ? FA2_FWD_D128_PF0 : FA2_FWD_D64_PF0;
     constexpr int ROFF = D == 128 ? FA2_FWD_D128_ROFF : FA2_FWD_D64_ROFF, TOFFV = D == 128 ? FA2_FWD_D128_TOFFV : FA2_FWD_D64_TOFFV;
+    constexpr int ST = D == 128 ? FA2_FWD_D128_STATE : FA2_FWD_D64_STATE;      // l0a l0b l1a l1b | rm0 rm1 | mb0 mb1 | th0 th1
     static_assert(NP % kF1Waves == 0 && TILEB == 16384, "DMA piece split");
 
     const int tid = threadIdx.x;
@@ -179,10 +186,11 @@ __global__ void __launch_bounds__(64 * kF1Waves, 1) __attribute__((amdgpu_num_vg
         });
     });
 
-    // ---- running state per row block: m_run (natural units), mb = m_run log2 e (0 while -inf), thr = raw score above
-    // which the lane asks for a new reference, l = two partial row sums of the lane
+    // ---- running state per row block.  m_run (the reference, natural units) and the deferred O scale are hipcc's; the row
+    // sums l (two partial sums per block), mb = m_run log2 e (0 while -inf) and thr = the raw score above which the lane asks
+    // for a new reference live in the registers the bodies name (ST ...) and are rewritten only by the rare update below.
     const float inv_scale = 1.0f / p.scale;
-    float m_run[2], mb[2], thr[2], l[2][2], rm[2] = {-INFINITY, -INFINITY}, pend[2] = {1.0f, 1.0f};
+    float m_run[2], pend[2] = {1.0f, 1.0f};
     bool have_pend = false;
     if (STATE && p.resume) {
         static_for<2>([&](auto QB) {
@@ -195,18 +203,22 @@ __global__ void __launch_bounds__(64 * kF1Waves, 1) __attribute__((amdgpu_num_vg
                 static_for<4>([&](auto E) { acc_write<A_O + (qb * DT + dt) * 16 + 4 * g + decltype(E)::value>(v[decltype(E)::value]); });
             });
             m_run[qb] = p.M[(size_t)head * qhs + qld];
-            l[qb][0] = h == 0 ? p.L[(size_t)head * qhs + qld] : 0.0f;
-            l[qb][1] = 0.0f;
-            mb[qb] = m_run[qb] == -INFINITY ? 0.0f : m_run[qb] * kLog2e;
-            thr[qb] = (m_run[qb] + kF1RescaleThr) * inv_scale;
+            f1_vsetf<ST + 2 * qb>(h == 0 ? p.L[(size_t)head * qhs + qld] : 0.0f);
+            f1_vsetf<ST + 2 * qb + 1>(0.0f);
+            f1_vsetf<ST + 6 + qb>(m_run[qb] == -INFINITY ? 0.0f : m_run[qb] * kLog2e);
+            f1_vsetf<ST + 8 + qb>((m_run[qb] + kF1RescaleThr) * inv_scale);
         });
     } else {
         const u32x4 z = {0u, 0u, 0u, 0u};
         static_for<2 * DT>([&](auto T) { f1_acc_zero<A_O + 16 * decltype(T)::value>(z); });
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            m_run[qb] = -INFINITY; mb[qb] = 0.0f; thr[qb] = -INFINITY; l[qb][0] = 0.0f; l[qb][1] = 0.0f;
-        }
+        static_for<2>([&](auto QB) {
+            constexpr int qb = decltype(QB)::value;
+            m_run[qb] = -INFINITY;
+            f1_vsetf<ST + 2 * qb>(0.0f);
+            f1_vsetf<ST + 2 * qb + 1>(0.0f);
+            f1_vsetf<ST + 6 + qb>(0.0f);
+            f1_vsetf<ST + 8 + qb>(-INFINITY);
+        });
     }
     // S sets and packed P of "the blocks before the first": exp2(-huge) = 0 and P = 0, so the first two bodies add exactly zero
     static_for<32>([&](auto R) {
@@ -254,9 +266,9 @@ __global__ void __launch_bounds__(64 * kF1Waves, 1) __attribute__((amdgpu_num_vg
         if (need) {
             asm volatile("; fa2-cold: new softmax reference");
             bool any_scale = false;
-#pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
-                const float mx = half_max(rm[qb]) * p.scale;
+            static_for<2>([&](auto QB) {
+                constexpr int qb = decltype(QB)::value;
+                const float mx = half_max(f1_vget<ST + 4 + qb>()) * p.scale;
                 const bool grow = mx > m_run[qb] + kF1RescaleThr;        // also true from m_run = -inf
                 const bool any_grow = __any(grow);
                 const float m_new = any_grow ? fmaxf(m_run[qb], mx) : m_run[qb];
@@ -264,49 +276,69 @@ __global__ void __launch_bounds__(64 * kF1Waves, 1) __attribute__((amdgpu_num_vg
                 const bool sc = any_grow && __any(m_run[qb] != -INFINITY && m_new != m_run[qb]);
                 const float alpha = m_new == -INFINITY ? 1.0f : __builtin_amdgcn_exp2f((m_run[qb] - m_new) * kLog2e);
                 m_run[qb] = m_new;
-                mb[qb] = m_new == -INFINITY ? 0.0f : m_new * kLog2e;      // a row with no visible key yet keeps p = 0
-                thr[qb] = (m_new + kF1RescaleThr) * inv_scale;
-                l[qb][0] *= alpha;
-                l[qb][1] *= alpha;
+                f1_vsetf<ST + 6 + qb>(m_new == -INFINITY ? 0.0f : m_new * kLog2e);      // a row with no visible key yet keeps p = 0
+                f1_vsetf<ST + 8 + qb>((m_new + kF1RescaleThr) * inv_scale);
+                f1_vsetf<ST + 2 * qb>(f1_vget<ST + 2 * qb>() * alpha);
+                f1_vsetf<ST + 2 * qb + 1>(f1_vget<ST + 2 * qb + 1>() * alpha);
                 pend[qb] = sc ? alpha : 1.0f;
                 any_scale = any_scale || sc;
-            }
+            });
             have_pend = any_scale;
         }
     };
 
-    auto run_tile = [&](auto B_, int t) {
+    // GENERAL = false: every body of the tile is known to exist and to be unmasked for this wave (no per-body decisions: the
+    // only code between two bodies is the test of the flag the body returns); GENERAL = true: tail, diagonal and drain tiles.
+    auto run_tile = [&](auto B_, auto GENERAL_, int t) {
         constexpr int B = decltype(B_)::value;
+        constexpr bool GENERAL = decltype(GENERAL_)::value;
+        dma.kso = (uint32_t)(((t + 2) * KV + wave * RPI) * ROWB);
         static_for<NH>([&](auto KB_) {
             constexpr int kb = decltype(KB_)::value;
             const int j = t * NH + kb;
-            if (j >= JB) return;                                  // wave- and workgroup-uniform
-            const int key0 = j * 32;
-            bool masked = key0 + 32 > Nk;
-            if (CAUSAL) masked = masked || key0 + 31 > q0 + p.causal_shift;
-            if constexpr (kb == NH - 1) dma.kso = (uint32_t)(((t + 2) * KV + wave * RPI) * ROWB);
             int need = 0;
-            if (masked) {
-                int hi[2];
+            if constexpr (GENERAL) {
+                if (j >= JB) return;                                  // wave- and workgroup-uniform
+                const int key0 = j * 32;
+                bool masked = key0 + 32 > Nk;
+                if (CAUSAL) masked = masked || key0 + 31 > q0 + p.causal_shift;
+                if (masked) {
+                    int hi[2];
 #pragma unroll
-                for (int qb = 0; qb < 2; ++qb) hi[qb] = (CAUSAL ? min(Nk, qrow[qb] + p.causal_shift + 1) : Nk) - key0 - 4 * h;
-                f1_body<D, B, kb, true>(c2, mb, l, rm, thr, need, hi, dma);
+                    for (int qb = 0; qb < 2; ++qb) hi[qb] = (CAUSAL ? min(Nk, qrow[qb] + p.causal_shift + 1) : Nk) - key0 - 4 * h;
+                    f1_body<D, B, kb, true>(c2, need, hi, dma);
+                } else {
+                    const int hi[2] = {0, 0};
+                    f1_body<D, B, kb, false>(c2, need, hi, dma);
+                }
             } else {
                 const int hi[2] = {0, 0};
-                f1_body<D, B, kb, false>(c2, mb, l, rm, thr, need, hi, dma);
+                f1_body<D, B, kb, false>(c2, need, hi, dma);
             }
-            if (need || have_pend) update(need);
+            // (both are SGPR values already; the readfirstlane tells hipcc that the branch is uniform)
+            if (__builtin_amdgcn_readfirstlane(need | (int)have_pend)) update(need);
         });
     };
-    const int ntl = (JB + NH - 1) / NH;
-    for (int t = 0; t < ntl; t += 4) {
-        run_tile(std::integral_constant<int, 0>{}, t);
+    const int ntl = (JB + NH - 1) / NH;                    // tiles with a body to run (the last ones partly)
+    // tiles whose every key is visible to every row of this WAVE: plain bodies, nothing to decide
+    int nfull = Nk / KV;
+    if (CAUSAL) nfull = min(nfull, max(0, (q0 + p.causal_shift + 1) / KV));
+    nfull = min(nfull, J / NH) & ~3;                       // whole rounds of the ring of four
+    int t = 0;
+    for (; t < nfull; t += 4) {
+        run_tile(std::integral_constant<int, 0>{}, std::false_type{}, t);
+        run_tile(std::integral_constant<int, 1>{}, std::false_type{}, t + 1);
+        run_tile(std::integral_constant<int, 2>{}, std::false_type{}, t + 2);
+        run_tile(std::integral_constant<int, 3>{}, std::false_type{}, t + 3);
+    }
+    for (; t < ntl; t += 4) {
+        run_tile(std::integral_constant<int, 0>{}, std::true_type{}, t);
         if (t + 1 >= ntl) break;
-        run_tile(std::integral_constant<int, 1>{}, t + 1);
+        run_tile(std::integral_constant<int, 1>{}, std::true_type{}, t + 1);
         if (t + 2 >= ntl) break;
-        run_tile(std::integral_constant<int, 2>{}, t + 2);
+        run_tile(std::integral_constant<int, 2>{}, std::true_type{}, t + 2);
         if (t + 3 >= ntl) break;
-        run_tile(std::integral_constant<int, 3>{}, t + 3);
+        run_tile(std::integral_constant<int, 3>{}, std::true_type{}, t + 3);
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // the last bodies' look-ahead DMA and reads
 
@@ -315,7 +347,7 @@ __global__ void __launch_bounds__(64 * kF1Waves, 1) __attribute__((amdgpu_num_vg
     const bool fin = !STATE || p.finalize;
     static_for<2>([&](auto QB) {
         constexpr int qb = decltype(QB)::value;
-        const float l_tot = half_sum(l[qb][0] + l[qb][1]);
+        const float l_tot = half_sum(f1_vget<ST + 2 * qb>() + f1_vget<ST + 2 * qb + 1>());
         const size_t qoff = (size_t)head * qhs + qrow[qb];
         const float pa = pend[qb];                 // an O rescale still pending from the last update (1 otherwise)
         const float inv = (fin ? (l_tot > 0.0f ? 1.0f / l_tot : 0.0f) : 1.0f) * pa;

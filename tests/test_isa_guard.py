@@ -27,7 +27,7 @@ CSRC = os.path.join(ROOT, "cuda_flashattention_amd", "csrc")
 def asm():
     subprocess.check_call(["make", "-s", "-j", "4", "-C", CSRC, "asm"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     out = {}
-    for f in ("fa2_fwd_bf16", "fa2_bwd_bf16", "fa2_bwd_fused", "fa2_fwd_fp8", "fa2_f32", "fa2_util", "fa1_f32"):
+    for f in ("fa2_fwd_bf16", "fa2_fwd1_bf16", "fa2_bwd_bf16", "fa2_bwd_fused", "fa2_fwd_fp8", "fa2_f32", "fa2_util", "fa1_f32"):
         out[f] = open(os.path.join(CSRC, "_obj", f + ".s")).read()
     return out
 
@@ -79,7 +79,7 @@ def _main_loop(body):
     return body[lo:hi]
 
 
-PRODUCT = ("fa2_fwd_bf16", "fa2_bwd_bf16", "fa2_bwd_fused", "fa2_fwd_fp8", "fa2_f32", "fa2_util", "fa1_f32")
+PRODUCT = ("fa2_fwd_bf16", "fa2_fwd1_bf16", "fa2_bwd_bf16", "fa2_bwd_fused", "fa2_fwd_fp8", "fa2_f32", "fa2_util", "fa1_f32")
 
 
 def test_no_scratch_no_spill(asm):
@@ -93,7 +93,8 @@ def test_no_scratch_no_spill(asm):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("file,pattern", [("fa2_fwd_bf16", "fa2_fwd_bf16_kernel"), ("fa2_bwd_bf16", "fa2_bwd_dq_kernel"),
+@pytest.mark.parametrize("file,pattern", [("fa2_fwd_bf16", "fa2_fwd_bf16_kernel"), ("fa2_fwd1_bf16", "fa2_fwd1_bf16_kernel"),
+                                          ("fa2_bwd_bf16", "fa2_bwd_dq_kernel"),
                                           ("fa2_bwd_bf16", "fa2_bwd_dkdv_kernel"), ("fa2_bwd_fused", "fa2_bwd_fused_kernelILb")])
 def test_accumulator_file_is_touched_by_asm_only(asm, file, pattern):
     """The kernels that name literal AGPRs: nothing hipcc generates may read, write, copy or spill an accumulator."""
@@ -123,6 +124,37 @@ def test_named_vgprs_are_the_bodies_own(asm, pattern, limit, top128, top64):
         assert k["meta"]["total"] == 512 and k["meta"]["agpr"] == 256, (name, k["meta"])
         used = max(int(m.group(1) or m.group(3)) for b in blocks for s in b for m in pat.finditer(s))
         assert used == (top128 if "ILi128E" in name else top64), (name, used)      # VEND - 1 of the generator
+
+
+def test_generated_forward_kernel(asm):
+    """fa2_fwd1_bf16_kernel (what fa2_forward runs for bf16) is compiled with amdgpu_num_vgpr(64): v64.. belong to the bodies
+    of tools/gen_fwd_body.py.  Per ring buffer and key block of a tile there is a plain and a masked body with 2 KS + 4 DT
+    MFMAs each; the bodies of a tile's last key block open with vmcnt(0) + s_barrier and carry the 8 LDS-DMA pieces of the
+    tile two ahead; nothing outside the asm regions names a body register."""
+    ks = {n: k for n, k in _kernels(asm["fa2_fwd1_bf16"]).items() if "fa2_fwd1_bf16_kernel" in n}
+    assert len(ks) == 8
+    pat = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+    for name, k in ks.items():
+        D = 128 if "ILi128E" in name else 64
+        nh, per_body = (2, 32) if D == 128 else (4, 16)
+        outside, blocks = _split_asm(k["body"])
+        for s in outside:
+            for m in pat.finditer(s):
+                hi = int(m.group(1)) if m.group(1) else int(m.group(3))
+                assert hi < 64, (name, s)
+        assert k["meta"]["total"] == 512 and k["meta"]["scratch"] == 0 and k["meta"]["vgpr_spill"] == 0, (name, k["meta"])
+        bodies = [b for b in blocks if sum("v_mfma_f32_32x32x16_bf16" in s for s in b) == per_body]
+        # the loop over whole unmasked rounds holds 4 nh plain bodies; the general loop 4 nh plain + 4 nh masked
+        assert len(bodies) == 12 * nh, (name, len(bodies))
+        with_barrier = [b for b in bodies if any(s.startswith("s_barrier") for s in b)]
+        assert len(with_barrier) == 12            # one per tile
+        for b in with_barrier:
+            assert b[0].startswith("s_waitcnt vmcnt(0)") and b[1].startswith("s_barrier")
+            assert sum(s.startswith("buffer_load_dwordx4") and s.endswith(" lds") for s in b) == 8
+        for b in bodies:
+            if b not in with_barrier:
+                assert not any("buffer_load" in s for s in b)
+        assert sum(any(s.startswith("v_cndmask_b32") for s in b) for b in bodies) == 4 * nh      # the masked variants
 
 
 def test_fused_backward_kernel(asm):
@@ -210,7 +242,7 @@ def test_fp8_loop_budget(asm):
             assert any("v_mfma_f32_32x32x64_f8f6f4" in l for l in _main_loop(k["body"]))
 
 
-@pytest.mark.parametrize("inc", ["fa2_bwd_dkdv_body.inc", "fa2_bwd_dq_body.inc", "fa2_bwd_fused_body.inc"])
+@pytest.mark.parametrize("inc", ["fa2_bwd_dkdv_body.inc", "fa2_bwd_dq_body.inc", "fa2_bwd_fused_body.inc", "fa2_fwd_body.inc"])
 def test_generated_bodies_pass_the_static_checker(inc):
     """tools/check_body.py replays every generated main-loop body twice in a row (steady state) with an in-order model of
     the LDS queue: each MFMA source delivered by an LDS read is covered by a counted lgkmcnt, no read overwrites a
@@ -222,7 +254,7 @@ def test_generated_bodies_pass_the_static_checker(inc):
     spec.loader.exec_module(cb)
     text = open(os.path.join(CSRC, inc)).read()
     names = re.findall(r"#define (FA2_\w+_[CM]?BODY_\w+) ", text)
-    assert len(names) in (12, 16, 18)
+    assert len(names) in (12, 16, 18, 48)
     for n in names:
         assert cb.check(cb.body(text, n), n) == []
 
@@ -230,7 +262,7 @@ def test_generated_bodies_pass_the_static_checker(inc):
 def test_generated_bodies_are_up_to_date(tmp_path):
     """The committed .inc files are what the generators produce (nobody edits them by hand, nobody forgets to regenerate)."""
     for gen, inc in (("gen_dkdv_body.py", "fa2_bwd_dkdv_body.inc"), ("gen_dq_body.py", "fa2_bwd_dq_body.inc"),
-                     ("gen_fused_body.py", "fa2_bwd_fused_body.inc")):
+                     ("gen_fused_body.py", "fa2_bwd_fused_body.inc"), ("gen_fwd_body.py", "fa2_fwd_body.inc")):
         out = tmp_path / inc
         subprocess.check_call(["python3", os.path.join(ROOT, "tools", gen), "--out", str(out)], cwd=os.path.join(ROOT, "tools"),
                               stdout=subprocess.DEVNULL)

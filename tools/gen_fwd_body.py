@@ -26,9 +26,11 @@ Registers (kernel compiled with amdgpu_num_vgpr(64): hipcc owns v0..v63):
     a[0 : 32 DT)        O^T tiles (qb, dt);      a[128 : 128 + 8 KS)  Q fragments (qb, s)
     v[64:128)           S sets: S^T(parity, qb), 16 registers each;  v[128:160) packed P: PF[parity][qb][sp], 4 each
     v[160:192)          eight fragment slots;  then ROFF (KS row-read addresses of the K ring), TOFFV (2 DT transposed-read
-                        addresses of the V ring) -- set once by the kernel
-Operands: %[c2] (s), %[mb0/1] (v: reference * log2 e of the lane's row in qb), %[l0a],[l0b],[l1a],[l1b] (+v: partial row
-sums), %[rm0/1] (=v: lane maxima of block j), %[th0/1] (v: raw-score thresholds), %[need] (=s: some lane is over), masked
+                        addresses of the V ring) -- set once by the kernel; then the softmax STATE, ten registers the kernel
+                        initialises and its rare update path rewrites: l0a l0b l1a l1b (partial row sums), rm0 rm1 (lane maxima
+                        of block j), mb0 mb1 (reference * log2 e of the lane's rows), th0 th1 (raw-score thresholds).  Keeping
+                        them out of hipcc's hands means no copies between the plain and the masked body variants.
+Operands: %[c2] (s), %[need] (=s: some lane's maximum is over its threshold), masked
 variant %[hi0/1] (v: first masked key of the lane's row, relative to the block and to the lane's half), %[ninf] (v: -inf);
 DMA bodies
 %[mw] (s: LDS byte address of the wave's first piece), %[dvo] (v), %[krs], %[vrs] (s x4), %[kso] (s: byte offset of the
@@ -65,7 +67,8 @@ class Regs:
         self.SLOT = V0 + 96
         self.ROFF = self.SLOT + 4 * NSLOT
         self.TOFFV = self.ROFF + self.KS
-        self.VEND = self.TOFFV + 2 * self.DT
+        self.STATE = self.TOFFV + 2 * self.DT      # l0a l0b l1a l1b | rm0 rm1 | mb0 mb1 | th0 th1
+        self.VEND = self.STATE + 10
         assert self.VEND <= 256
 
     def s(self, par, qb): b = self.SET[par] + 16 * qb; return f"v[{b}:{b + 15}]"
@@ -77,6 +80,10 @@ class Regs:
     def slot_hi(self, i): b = self.SLOT + 4 * i + 2; return f"v[{b}:{b + 1}]"
     def roff(self, s): return f"v{self.ROFF + s}"
     def toffv(self, i): return f"v{self.TOFFV + i}"
+    def l(self, qb, e): return f"v{self.STATE + 2 * qb + e}"
+    def rm(self, qb): return f"v{self.STATE + 4 + qb}"
+    def mb(self, qb): return f"v{self.STATE + 6 + qb}"
+    def th(self, qb): return f"v{self.STATE + 8 + qb}"
     def qf(self, qb, s): b = A_QF + 4 * (qb * self.KS + s); return f"a[{b}:{b + 3}]"
     def o(self, qb, dt): b = A_O + 16 * (qb * self.DT + dt); return f"a[{b}:{b + 15}]"
 
@@ -158,9 +165,9 @@ def build(D, par, masked, dma):
                 k += 1
                 pair = []
                 for e, r in enumerate((8 * sp + 2 * j, 8 * sp + 2 * j + 1)):
-                    f = valu(f"v_fma_f32 {R.sreg(op, qb, r)}, {R.sreg(op, qb, r)}, %[c2], -%[mb{qb}]", "valu", rel, max(dl - 2, rel))
+                    f = valu(f"v_fma_f32 {R.sreg(op, qb, r)}, {R.sreg(op, qb, r)}, %[c2], -{R.mb(qb)}", "valu", rel, max(dl - 2, rel))
                     x = valu(f"v_exp_f32 {R.sreg(op, qb, r)}, {R.sreg(op, qb, r)}", "exp", rel, max(dl - 1, rel), after=[f])
-                    valu(f"v_add_f32 %[l{qb}{'ab'[e]}], %[l{qb}{'ab'[e]}], {R.sreg(op, qb, r)}", "valu", rel, dl, after=[x])
+                    valu(f"v_add_f32 {R.l(qb, e)}, {R.l(qb, e)}, {R.sreg(op, qb, r)}", "valu", rel, dl, after=[x])
                     pair.append(x)
                 valu(f"v_cvt_pk_bf16_f32 {R.pfw(op, qb, sp, j)}, {R.sreg(op, qb, 8 * sp + 2 * j)}, {R.sreg(op, qb, 8 * sp + 2 * j + 1)}",
                      "cvt", rel, dl, after=pair)
@@ -178,11 +185,11 @@ def build(D, par, masked, dma):
                                 "cmp", rel, NS - 3)
         for i in range(8):
             a, b = R.sreg(par, qb, 2 * i), R.sreg(par, qb, 2 * i + 1)
-            text = f"v_max_f32 %[rm{qb}], {a}, {b}" if i == 0 else f"v_max3_f32 %[rm{qb}], %[rm{qb}], {a}, {b}"
+            text = f"v_max_f32 {R.rm(qb)}, {a}, {b}" if i == 0 else f"v_max3_f32 {R.rm(qb)}, {R.rm(qb)}, {a}, {b}"
             dep = ([prev] if prev else []) + ([masks[2 * i], masks[2 * i + 1]] if masked else [])
             prev = valu(text, "valu", rel, NS - 2, after=dep)
         last.append(prev)
-    valu("v_cmp_gt_f32 vcc, %[rm0], %[th0]\n\tv_cmp_gt_f32 s[10:11], %[rm1], %[th1]\n\ts_or_b64 vcc, vcc, s[10:11]\n\t"
+    valu(f"v_cmp_gt_f32 vcc, {R.rm(0)}, {R.th(0)}\n\tv_cmp_gt_f32 s[10:11], {R.rm(1)}, {R.th(1)}\n\ts_or_b64 vcc, vcc, s[10:11]\n\t"
          "s_or_b32 %[need], vcc_lo, vcc_hi", "cmp", NS - 2, NS - 1, after=last)
 
     # ---- LDS-DMA of tile t + 2 (bodies of a tile's last key block only): piece i of tensor `which` for this wave
@@ -250,7 +257,7 @@ def main():
         budget = int(os.environ.get("FA2_GEN_BUDGET_FWD%d" % D, "24" if D == 128 else "44"))
         chunks.append(f"#define FA2_FWD_D{D}_SET0 {R0.SET[0]}\n#define FA2_FWD_D{D}_SET1 {R0.SET[1]}\n#define FA2_FWD_D{D}_PF0 {R0.PF[0]}\n"
                       f"#define FA2_FWD_D{D}_ROFF {R0.ROFF}\n#define FA2_FWD_D{D}_TOFFV {R0.TOFFV}\n#define FA2_FWD_D{D}_VEND {R0.VEND}\n"
-                      f"#define FA2_FWD_D{D}_KV {R0.KV}\n")
+                      f"#define FA2_FWD_D{D}_KV {R0.KV}\n#define FA2_FWD_D{D}_STATE {R0.STATE}\n")
         pros = set()
         for masked in (0, 1):
             for kb in range(R0.NH):
