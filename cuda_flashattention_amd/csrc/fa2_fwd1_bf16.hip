@@ -29,32 +29,48 @@ namespace fa2 {
 
 #include "fa2_fwd_body.inc"
 
-constexpr int kF1Waves = 4;
-constexpr int kF1Rows = 64 * kF1Waves;      // query rows per workgroup
+constexpr int kF1Rows = 256;                 // query rows per workgroup (4 waves x 64 or 8 waves x 32)
 constexpr int kF1Bufs = 4;                  // LDS ring depth (tools/gen_fwd_body.py: NBUF)
 constexpr float kF1RescaleThr = 6.0f;       // natural-log units of the scaled score
 
 typedef __attribute__((address_space(3))) void* f1_lptr_t;
 
-template <int R>
+// Two shapes of the same kernel (tools/gen_fwd_body.py: CONFIGS):
+//   QBS = 2  one wave per SIMD: 4 waves x 64 rows, 512 registers per wave (hipcc: v0..v63), a[0:256)
+//   QBS = 1  two waves per SIMD: 8 waves x 32 rows, 128 + 128 registers per wave (hipcc: v0..v39), a[0:128) -- for d = 64,
+//            where the VALU (4 instructions per S element against half the MFMAs of d = 128) is the bound and two waves
+//            issue VALU instructions at ~4.4 clocks each against ~7 for one wave alone (tools/probes/softmax_port.hip)
+#define FA2_ACC128_LIST                                                                                                        \
+    "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", \
+    "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37",     \
+    "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55",     \
+    "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73",     \
+    "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91",     \
+    "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108",   \
+    "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124",   \
+    "a125", "a126", "a127"
+#define FA2_F1_REGS2 "v255", FA2_ACC_CLOBBERS
+#define FA2_F1_REGS1 "v127", FA2_ACC128_LIST
+#define FA2_F1_MISC "memory", "vcc", "scc", "s10", "s11", "s12", "m0"
+
+// every asm statement below exists twice: with the register-file clobbers of the one-wave and of the two-wave shape
+#define FA2_F1_ASM(QBS, TEXT, OUTS, INS)                                                  \
+    do {                                                                                   \
+        if constexpr (QBS == 2) asm volatile(TEXT : OUTS : INS : FA2_F1_MISC, FA2_F1_REGS2); \
+        else asm volatile(TEXT : OUTS : INS : FA2_F1_MISC, FA2_F1_REGS1);                  \
+    } while (0)
+#define FA2_F1_COMMA ,
+
+template <int QBS, int R>
 __device__ __forceinline__ void f1_vset(uint32_t x)
 {
-    asm volatile("v_mov_b32 v%c1, %0" : : "v"(x), "i"(R) : "v255");
+    FA2_F1_ASM(QBS, "v_mov_b32 v%c1, %0", , "v"(x) FA2_F1_COMMA "i"(R));
 }
-template <int R>
+template <int QBS, int R>
 __device__ __forceinline__ void f1_vsetf(float x)
 {
-    asm volatile("v_mov_b32 v%c1, %0" : : "v"(x), "i"(R) : "v255");
+    FA2_F1_ASM(QBS, "v_mov_b32 v%c1, %0", , "v"(x) FA2_F1_COMMA "i"(R));
 }
-
-#define FA2_F1_CLOBBERS "memory", "vcc", "scc", "s10", "s11", "s12", "m0", "v255", FA2_ACC_CLOBBERS
-
-struct F1Dma {
-    __amdgpu_buffer_rsrc_t krs, vrs;
-    uint32_t mw, dvo, kso;
-};
-
-// One body.  KB < NH - 1: plain; KB == NH - 1: starts with the tile barrier and issues the DMA of tile t + 2.
 template <int R>
 __device__ __forceinline__ float f1_vget()
 {
@@ -62,58 +78,107 @@ __device__ __forceinline__ float f1_vget()
     asm volatile("v_mov_b32 %0, v%c1" : "=v"(x) : "i"(R));
     return x;
 }
+template <int QBS, int R>
+__device__ __forceinline__ void f1_awrite(float x)
+{
+    FA2_F1_ASM(QBS, "v_accvgpr_write_b32 a[%c1], %0", , "v"(x) FA2_F1_COMMA "i"(R));
+}
+template <int R>
+__device__ __forceinline__ float f1_aread()
+{
+    float x;
+    asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(x) : "i"(R));
+    return x;
+}
+template <int QBS, int LO>
+__device__ __forceinline__ void f1_awrite_frag(bf16x8 f)
+{
+    const u32x4 w = __builtin_bit_cast(u32x4, f);
+    FA2_F1_ASM(QBS, "v_accvgpr_write_b32 a[%c4], %0\n\tv_accvgpr_write_b32 a[%c5], %1\n\tv_accvgpr_write_b32 a[%c6], %2\n\t"
+                    "v_accvgpr_write_b32 a[%c7], %3", ,
+               "v"(w[0]) FA2_F1_COMMA "v"(w[1]) FA2_F1_COMMA "v"(w[2]) FA2_F1_COMMA "v"(w[3]) FA2_F1_COMMA "i"(LO) FA2_F1_COMMA "i"(LO + 1)
+                   FA2_F1_COMMA "i"(LO + 2) FA2_F1_COMMA "i"(LO + 3));
+}
+// four accumulator registers *= alpha (per lane = per query row)
+template <int QBS, int R>
+__device__ __forceinline__ void f1_scale4(float alpha)
+{
+    float t0, t1, t2, t3;
+    FA2_F1_ASM(QBS, "v_accvgpr_read_b32 %0, a[%c5]\n\tv_accvgpr_read_b32 %1, a[%c6]\n\t"
+                    "v_accvgpr_read_b32 %2, a[%c7]\n\tv_accvgpr_read_b32 %3, a[%c8]\n\t"
+                    "v_mul_f32 %0, %0, %4\n\tv_mul_f32 %1, %1, %4\n\tv_mul_f32 %2, %2, %4\n\tv_mul_f32 %3, %3, %4\n\t"
+                    "v_accvgpr_write_b32 a[%c5], %0\n\tv_accvgpr_write_b32 a[%c6], %1\n\t"
+                    "v_accvgpr_write_b32 a[%c7], %2\n\tv_accvgpr_write_b32 a[%c8], %3",
+               "=&v"(t0) FA2_F1_COMMA "=&v"(t1) FA2_F1_COMMA "=&v"(t2) FA2_F1_COMMA "=&v"(t3),
+               "v"(alpha) FA2_F1_COMMA "i"(R) FA2_F1_COMMA "i"(R + 1) FA2_F1_COMMA "i"(R + 2) FA2_F1_COMMA "i"(R + 3));
+}
+template <int QBS, int R>
+__device__ __forceinline__ void f1_acc_zero(u32x4 z)
+{
+    FA2_F1_ASM(QBS, "s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[%c1:%c2], %0, %0, 0", , "v"(z) FA2_F1_COMMA "i"(R) FA2_F1_COMMA "i"(R + 15));
+}
 
-template <int D, int BUF, int KB, bool MASKED>
+struct F1Dma {
+    __amdgpu_buffer_rsrc_t krs, vrs;
+    uint32_t mw, dvo, kso;
+};
+
+// One body.  KB < NH - 1: plain; KB == NH - 1: starts with the tile barrier and issues the DMA of tile t + 2.
+template <int D, int QBS, int BUF, int KB, bool MASKED>
 __device__ __forceinline__ void f1_body(float c2, int& need, const int (&hi)[2], const F1Dma& dma)
 {
-#define FA2_F1_CASE(DD, B, K, M)                                                                                                  \
-    if constexpr (D == DD && BUF == B && KB == K && MASKED == bool(M))                                                              \
-        asm volatile(FA2_FWD_BODY_D##DD##_B##B##_K##K##_M##M                                                                        \
-                     : [need] "=&s"(need)                                                                                            \
-                     : [c2] "s"(c2), [hi0] "v"(hi[0]), [hi1] "v"(hi[1]), [ninf] "v"(-INFINITY), [mw] "s"(dma.mw), [dvo] "v"(dma.dvo),      \
-                       [krs] "s"(dma.krs), [vrs] "s"(dma.vrs), [kso] "s"(dma.kso)                                                     \
-                     : FA2_F1_CLOBBERS);
-#define FA2_F1_CASES_B(DD, K, M) FA2_F1_CASE(DD, 0, K, M) FA2_F1_CASE(DD, 1, K, M) FA2_F1_CASE(DD, 2, K, M) FA2_F1_CASE(DD, 3, K, M)
-    FA2_F1_CASES_B(128, 0, 0) FA2_F1_CASES_B(128, 1, 0) FA2_F1_CASES_B(128, 0, 1) FA2_F1_CASES_B(128, 1, 1)
-    FA2_F1_CASES_B(64, 0, 0) FA2_F1_CASES_B(64, 1, 0) FA2_F1_CASES_B(64, 2, 0) FA2_F1_CASES_B(64, 3, 0)
-    FA2_F1_CASES_B(64, 0, 1) FA2_F1_CASES_B(64, 1, 1) FA2_F1_CASES_B(64, 2, 1) FA2_F1_CASES_B(64, 3, 1)
+#define FA2_F1_CASE(TAG, DD, QQ, B, K, M)                                                                                          \
+    if constexpr (D == DD && QBS == QQ && BUF == B && KB == K && MASKED == bool(M))                                                  \
+        FA2_F1_ASM(QQ, FA2_FWD_BODY_##TAG##_B##B##_K##K##_M##M, [need] "=&s"(need),                                                    \
+                   [c2] "s"(c2) FA2_F1_COMMA [hi0] "v"(hi[0]) FA2_F1_COMMA [hi1] "v"(hi[1]) FA2_F1_COMMA [ninf] "v"(-INFINITY)           \
+                       FA2_F1_COMMA [mw] "s"(dma.mw) FA2_F1_COMMA [dvo] "v"(dma.dvo) FA2_F1_COMMA [krs] "s"(dma.krs)                     \
+                       FA2_F1_COMMA [vrs] "s"(dma.vrs) FA2_F1_COMMA [kso] "s"(dma.kso));
+#define FA2_F1_CASES_B(TAG, DD, QQ, K, M) \
+    FA2_F1_CASE(TAG, DD, QQ, 0, K, M) FA2_F1_CASE(TAG, DD, QQ, 1, K, M) FA2_F1_CASE(TAG, DD, QQ, 2, K, M) FA2_F1_CASE(TAG, DD, QQ, 3, K, M)
+    FA2_F1_CASES_B(D128Q2, 128, 2, 0, 0) FA2_F1_CASES_B(D128Q2, 128, 2, 1, 0) FA2_F1_CASES_B(D128Q2, 128, 2, 0, 1) FA2_F1_CASES_B(D128Q2, 128, 2, 1, 1)
+    FA2_F1_CASES_B(D64Q2, 64, 2, 0, 0) FA2_F1_CASES_B(D64Q2, 64, 2, 1, 0) FA2_F1_CASES_B(D64Q2, 64, 2, 2, 0) FA2_F1_CASES_B(D64Q2, 64, 2, 3, 0)
+    FA2_F1_CASES_B(D64Q2, 64, 2, 0, 1) FA2_F1_CASES_B(D64Q2, 64, 2, 1, 1) FA2_F1_CASES_B(D64Q2, 64, 2, 2, 1) FA2_F1_CASES_B(D64Q2, 64, 2, 3, 1)
+    FA2_F1_CASES_B(D64Q1, 64, 1, 0, 0) FA2_F1_CASES_B(D64Q1, 64, 1, 1, 0) FA2_F1_CASES_B(D64Q1, 64, 1, 2, 0) FA2_F1_CASES_B(D64Q1, 64, 1, 3, 0)
+    FA2_F1_CASES_B(D64Q1, 64, 1, 0, 1) FA2_F1_CASES_B(D64Q1, 64, 1, 1, 1) FA2_F1_CASES_B(D64Q1, 64, 1, 2, 1) FA2_F1_CASES_B(D64Q1, 64, 1, 3, 1)
 #undef FA2_F1_CASES_B
 #undef FA2_F1_CASE
 }
 
-template <int D>
+template <int D, int QBS>
 __device__ __forceinline__ void f1_prologue()
 {
-    if constexpr (D == 128) asm volatile(FA2_FWD_PRO_D128 : : : FA2_F1_CLOBBERS);
-    else asm volatile(FA2_FWD_PRO_D64 : : : FA2_F1_CLOBBERS);
+    if constexpr (D == 128) FA2_F1_ASM(2, FA2_FWD_PRO_D128Q2, , );
+    else if constexpr (QBS == 2) FA2_F1_ASM(2, FA2_FWD_PRO_D64Q2, , );
+    else FA2_F1_ASM(1, FA2_FWD_PRO_D64Q1, , );
 }
 
-// O^T tiles of row block QB (DT x 16 accumulator registers) *= alpha (per lane = per query row)
-template <int R>
-__device__ __forceinline__ void f1_scale4(float alpha)
-{
-    float t0, t1, t2, t3;
-    asm volatile("v_accvgpr_read_b32 %0, a[%c5]\n\tv_accvgpr_read_b32 %1, a[%c6]\n\t"
-                 "v_accvgpr_read_b32 %2, a[%c7]\n\tv_accvgpr_read_b32 %3, a[%c8]\n\t"
-                 "v_mul_f32 %0, %0, %4\n\tv_mul_f32 %1, %1, %4\n\tv_mul_f32 %2, %2, %4\n\tv_mul_f32 %3, %3, %4\n\t"
-                 "v_accvgpr_write_b32 a[%c5], %0\n\tv_accvgpr_write_b32 a[%c6], %1\n\t"
-                 "v_accvgpr_write_b32 a[%c7], %2\n\tv_accvgpr_write_b32 a[%c8], %3"
-                 : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
-                 : "v"(alpha), "i"(R), "i"(R + 1), "i"(R + 2), "i"(R + 3) : FA2_ACC_CLOBBERS);
-}
+// generator constants of a configuration
+template <int D, int QBS> struct F1Map;
+template <> struct F1Map<128, 2> {
+    static constexpr int KV = FA2_FWD_D128Q2_KV, SET0 = FA2_FWD_D128Q2_SET0, SET1 = FA2_FWD_D128Q2_SET1, PF0 = FA2_FWD_D128Q2_PF0,
+                         ROFF = FA2_FWD_D128Q2_ROFF, TOFFV = FA2_FWD_D128Q2_TOFFV, ST = FA2_FWD_D128Q2_STATE, V0 = FA2_FWD_D128Q2_V0,
+                         A_QF = FA2_FWD_D128Q2_A_QF;
+};
+template <> struct F1Map<64, 2> {
+    static constexpr int KV = FA2_FWD_D64Q2_KV, SET0 = FA2_FWD_D64Q2_SET0, SET1 = FA2_FWD_D64Q2_SET1, PF0 = FA2_FWD_D64Q2_PF0,
+                         ROFF = FA2_FWD_D64Q2_ROFF, TOFFV = FA2_FWD_D64Q2_TOFFV, ST = FA2_FWD_D64Q2_STATE, V0 = FA2_FWD_D64Q2_V0,
+                         A_QF = FA2_FWD_D64Q2_A_QF;
+};
+template <> struct F1Map<64, 1> {
+    static constexpr int KV = FA2_FWD_D64Q1_KV, SET0 = FA2_FWD_D64Q1_SET0, SET1 = FA2_FWD_D64Q1_SET1, PF0 = FA2_FWD_D64Q1_PF0,
+                         ROFF = FA2_FWD_D64Q1_ROFF, TOFFV = FA2_FWD_D64Q1_TOFFV, ST = FA2_FWD_D64Q1_STATE, V0 = FA2_FWD_D64Q1_V0,
+                         A_QF = FA2_FWD_D64Q1_A_QF;
+};
 
-template <int R>
-__device__ __forceinline__ void f1_acc_zero(u32x4 z)
-{
-    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[%c1:%c2], %0, %0, 0" : : "v"(z), "i"(R), "i"(R + 15) : FA2_ACC_CLOBBERS);
-}
-
-template <int D, bool CAUSAL, bool STATE>
-__global__ void __launch_bounds__(64 * kF1Waves, 1) __attribute__((amdgpu_num_vgpr(64))) fa2_fwd1_bf16_kernel(FwdArgs p)
+template <int D, int QBS, bool CAUSAL, bool STATE>
+__device__ __forceinline__ void fa2_fwd1_impl(const FwdArgs& p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWB = D * 2;
-    constexpr int KV = D == 128 ? FA2_FWD_D128_KV : FA2_FWD_D64_KV;      // keys per tile
+    using M = F1Map<D, QBS>;
+    constexpr int kF1Waves = 8 / QBS;                                    // 4 waves x 64 rows or 8 waves x 32 rows
+    constexpr int WROWS = 32 * QBS;                                      // query rows per wave
+    constexpr int KV = M::KV;                                            // keys per tile
     constexpr int NH = KV / 32;                                          // key blocks (bodies) per tile
     constexpr int TILEB = KV * ROWB;                                     // 16 KiB either way
     constexpr int KRING = kF1Bufs * TILEB;                               // LDS: [4 K tiles][4 V tiles]
@@ -121,11 +186,10 @@ __global__ void __launch_bounds__(64 * kF1Waves, 1) __attribute__((amdgpu_num_vg
     constexpr int RPI = 64 / CPR;                                        // rows per 1-KiB DMA piece
     constexpr int NP = KV / RPI;                                         // pieces per tensor per tile (16)
     constexpr int KS = D / 16, DT = D / 32;
-    constexpr int A_O = 0, A_QF = 128;
-    constexpr int SET0 = D == 128 ? FA2_FWD_D128_SET0 : FA2_FWD_D64_SET0, SET1 = D == 128 ? FA2_FWD_D128_SET1 : FA2_FWD_D64_SET1;
-    constexpr int PF0 = D == 128 ? FA2_FWD_D128_PF0 : FA2_FWD_D64_PF0;
-    constexpr int ROFF = D == 128 ? FA2_FWD_D128_ROFF : FA2_FWD_D64_ROFF, TOFFV = D == 128 ? FA2_FWD_D128_TOFFV : FA2_FWD_D64_TOFFV;
-    constexpr int ST = D == 128 ? FA2_FWD_D128_STATE : FA2_FWD_D64_STATE;      // l0a l0b l1a l1b | rm0 rm1 | mb0 mb1 | th0 th1
+    constexpr int A_O = 0, A_QF = M::A_QF;
+    constexpr int SET0 = M::SET0, SET1 = M::SET1, PF0 = M::PF0, ROFF = M::ROFF, TOFFV = M::TOFFV;
+    constexpr int ST = M::ST;                                            // l (2 per row block) | rm | mb | th (1 per row block each)
+    constexpr int ST_RM = ST + 2 * QBS, ST_MB = ST + 3 * QBS, ST_TH = ST + 4 * QBS;
     static_assert(NP % kF1Waves == 0 && TILEB == 16384, "DMA piece split");
 
     const int tid = threadIdx.x;
@@ -144,7 +208,7 @@ __global__ void __launch_bounds__(64 * kF1Waves, 1) __attribute__((amdgpu_num_vg
     const char* Qh = (const char*)p.Q + (size_t)head * qhs * ROWB;
     const char* Kh = (const char*)p.K + (size_t)head * khs * ROWB;
     const char* Vh = (const char*)p.V + (size_t)head * khs * ROWB;
-    const int q0 = rb * kF1Rows + wave * 64;              // first query row of this wave
+    const int q0 = rb * kF1Rows + wave * WROWS;           // first query row of this wave
 
     // key blocks that hold a visible key for some row of the WORKGROUP (the tile barriers need every wave in every body);
     // two more bodies drain the pipeline (their S^T is masked completely: P = 0)
@@ -175,14 +239,14 @@ __global__ void __launch_bounds__(64 * kF1Waves, 1) __attribute__((amdgpu_num_vg
     stage(0, 3);          // "the tile before the first": read by the first bodies' P stage (against P = 0): must be finite
 
     // ---- Q fragments -> AGPRs; lane holds Q[q][16 s + 8 h .. +7] of rows q0 + 32 qb + qi
-    int qrow[2];
-    static_for<2>([&](auto QB) {
+    int qrow[QBS];
+    static_for<QBS>([&](auto QB) {
         constexpr int qb = decltype(QB)::value;
         qrow[qb] = q0 + 32 * qb + qi;
         const int qld = qrow[qb] < Nq ? qrow[qb] : Nq - 1;
         static_for<KS>([&](auto S) {
             constexpr int sidx = decltype(S)::value;
-            acc_write_frag<A_QF + (qb * KS + sidx) * 4>(*reinterpret_cast<const bf16x8*>(Qh + (size_t)qld * ROWB + 16 * (2 * sidx + h)));
+            f1_awrite_frag<QBS, A_QF + (qb * KS + sidx) * 4>(*reinterpret_cast<const bf16x8*>(Qh + (size_t)qld * ROWB + 16 * (2 * sidx + h)));
         });
     });
 
@@ -190,41 +254,43 @@ __global__ void __launch_bounds__(64 * kF1Waves, 1) __attribute__((amdgpu_num_vg
     // sums l (two partial sums per block), mb = m_run log2 e (0 while -inf) and thr = the raw score above which the lane asks
     // for a new reference live in the registers the bodies name (ST ...) and are rewritten only by the rare update below.
     const float inv_scale = 1.0f / p.scale;
-    float m_run[2], pend[2] = {1.0f, 1.0f};
+    float m_run[QBS], pend[QBS];
+#pragma unroll
+    for (int qb = 0; qb < QBS; ++qb) pend[qb] = 1.0f;
     bool have_pend = false;
     if (STATE && p.resume) {
-        static_for<2>([&](auto QB) {
+        static_for<QBS>([&](auto QB) {
             constexpr int qb = decltype(QB)::value;
             const int qld = qrow[qb] < Nq ? qrow[qb] : Nq - 1;
             const float* Oa = p.Oacc + ((size_t)head * qhs + qld) * D;
             static_for<4 * DT>([&](auto G) {
                 constexpr int dt = decltype(G)::value / 4, g = decltype(G)::value % 4;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(Oa + 32 * dt + 8 * g + 4 * h);
-                static_for<4>([&](auto E) { acc_write<A_O + (qb * DT + dt) * 16 + 4 * g + decltype(E)::value>(v[decltype(E)::value]); });
+                static_for<4>([&](auto E) { f1_awrite<QBS, A_O + (qb * DT + dt) * 16 + 4 * g + decltype(E)::value>(v[decltype(E)::value]); });
             });
             m_run[qb] = p.M[(size_t)head * qhs + qld];
-            f1_vsetf<ST + 2 * qb>(h == 0 ? p.L[(size_t)head * qhs + qld] : 0.0f);
-            f1_vsetf<ST + 2 * qb + 1>(0.0f);
-            f1_vsetf<ST + 6 + qb>(m_run[qb] == -INFINITY ? 0.0f : m_run[qb] * kLog2e);
-            f1_vsetf<ST + 8 + qb>((m_run[qb] + kF1RescaleThr) * inv_scale);
+            f1_vsetf<QBS, ST + 2 * qb>(h == 0 ? p.L[(size_t)head * qhs + qld] : 0.0f);
+            f1_vsetf<QBS, ST + 2 * qb + 1>(0.0f);
+            f1_vsetf<QBS, ST_MB + qb>(m_run[qb] == -INFINITY ? 0.0f : m_run[qb] * kLog2e);
+            f1_vsetf<QBS, ST_TH + qb>((m_run[qb] + kF1RescaleThr) * inv_scale);
         });
     } else {
         const u32x4 z = {0u, 0u, 0u, 0u};
-        static_for<2 * DT>([&](auto T) { f1_acc_zero<A_O + 16 * decltype(T)::value>(z); });
-        static_for<2>([&](auto QB) {
+        static_for<QBS * DT>([&](auto T) { f1_acc_zero<QBS, A_O + 16 * decltype(T)::value>(z); });
+        static_for<QBS>([&](auto QB) {
             constexpr int qb = decltype(QB)::value;
             m_run[qb] = -INFINITY;
-            f1_vsetf<ST + 2 * qb>(0.0f);
-            f1_vsetf<ST + 2 * qb + 1>(0.0f);
-            f1_vsetf<ST + 6 + qb>(0.0f);
-            f1_vsetf<ST + 8 + qb>(-INFINITY);
+            f1_vsetf<QBS, ST + 2 * qb>(0.0f);
+            f1_vsetf<QBS, ST + 2 * qb + 1>(0.0f);
+            f1_vsetf<QBS, ST_MB + qb>(0.0f);
+            f1_vsetf<QBS, ST_TH + qb>(-INFINITY);
         });
     }
     // S sets and packed P of "the blocks before the first": exp2(-huge) = 0 and P = 0, so the first two bodies add exactly zero
-    static_for<32>([&](auto R) {
-        f1_vsetf<SET0 + decltype(R)::value>(-1.0e30f);
-        f1_vsetf<SET1 + decltype(R)::value>(-1.0e30f);
-        f1_vset<PF0 + decltype(R)::value>(0u);
+    static_for<16 * QBS>([&](auto R) {
+        f1_vsetf<QBS, SET0 + decltype(R)::value>(-1.0e30f);
+        f1_vsetf<QBS, SET1 + decltype(R)::value>(-1.0e30f);
+        f1_vset<QBS, PF0 + decltype(R)::value>(0u);
     });
 
     // ---- loop-invariant LDS addresses into the registers the bodies name
@@ -233,11 +299,11 @@ __global__ void __launch_bounds__(64 * kF1Waves, 1) __attribute__((amdgpu_num_vg
         const int trq = (lane & 15) >> 2, trp = lane & 3, trcb = (lane >> 4) & 1;
         static_for<KS>([&](auto S) {
             constexpr int sidx = decltype(S)::value;
-            f1_vset<ROFF + sidx>(lbase + lds_off<D>(qi, 2 * sidx + h));
+            f1_vset<QBS, ROFF + sidx>(lbase + lds_off<D>(qi, 2 * sidx + h));
         });
         static_for<2 * DT>([&](auto I) {
             constexpr int dt = decltype(I)::value / 2, jj = decltype(I)::value % 2;
-            f1_vset<TOFFV + decltype(I)::value>(lbase + KRING + lds_off<D>(8 * jj + 4 * h + trq, 4 * dt + 2 * trcb + (trp >> 1)) + 8 * (trp & 1));
+            f1_vset<QBS, TOFFV + decltype(I)::value>(lbase + KRING + lds_off<D>(8 * jj + 4 * h + trq, 4 * dt + 2 * trcb + (trp >> 1)) + 8 * (trp & 1));
         });
     }
     const float c2 = p.scale * kLog2e;
@@ -249,16 +315,22 @@ __global__ void __launch_bounds__(64 * kF1Waves, 1) __attribute__((amdgpu_num_vg
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                         // tiles 0 and 1 have landed
-    f1_prologue<D>();
+#ifndef FA2_F1_NO_SETPRIO
+    // two waves per SIMD: the later-dispatched half of the workgroup loses every issue arbitration to the older half
+    // (priority, then age); one static priority bump for that half evens them out (MI355X_MICROARCH.md, 'Two waves per SIMD')
+    if constexpr (QBS == 1)
+        if (wave >= kF1Waves / 2) __builtin_amdgcn_s_setprio(1);
+#endif
+    f1_prologue<D, QBS>();
 
     // ---- the rare path between two bodies: first the O^T rescale left over from the previous update, then a new reference
     auto update = [&](int need) {
         if (have_pend) {
             asm volatile("; fa2-cold: deferred O rescale");
             mfma_acc_settle();
-            static_for<2>([&](auto QB) {
+            static_for<QBS>([&](auto QB) {
                 constexpr int qb = decltype(QB)::value;
-                static_for<4 * DT>([&](auto R4) { f1_scale4<A_O + qb * DT * 16 + 4 * decltype(R4)::value>(pend[qb]); });
+                static_for<4 * DT>([&](auto R4) { f1_scale4<QBS, A_O + qb * DT * 16 + 4 * decltype(R4)::value>(pend[qb]); });
                 pend[qb] = 1.0f;
             });
             have_pend = false;
@@ -266,9 +338,9 @@ __global__ void __launch_bounds__(64 * kF1Waves, 1) __attribute__((amdgpu_num_vg
         if (need) {
             asm volatile("; fa2-cold: new softmax reference");
             bool any_scale = false;
-            static_for<2>([&](auto QB) {
+            static_for<QBS>([&](auto QB) {
                 constexpr int qb = decltype(QB)::value;
-                const float mx = half_max(f1_vget<ST + 4 + qb>()) * p.scale;
+                const float mx = half_max(f1_vget<ST_RM + qb>()) * p.scale;
                 const bool grow = mx > m_run[qb] + kF1RescaleThr;        // also true from m_run = -inf
                 const bool any_grow = __any(grow);
                 const float m_new = any_grow ? fmaxf(m_run[qb], mx) : m_run[qb];
@@ -276,10 +348,10 @@ __global__ void __launch_bounds__(64 * kF1Waves, 1) __attribute__((amdgpu_num_vg
                 const bool sc = any_grow && __any(m_run[qb] != -INFINITY && m_new != m_run[qb]);
                 const float alpha = m_new == -INFINITY ? 1.0f : __builtin_amdgcn_exp2f((m_run[qb] - m_new) * kLog2e);
                 m_run[qb] = m_new;
-                f1_vsetf<ST + 6 + qb>(m_new == -INFINITY ? 0.0f : m_new * kLog2e);      // a row with no visible key yet keeps p = 0
-                f1_vsetf<ST + 8 + qb>((m_new + kF1RescaleThr) * inv_scale);
-                f1_vsetf<ST + 2 * qb>(f1_vget<ST + 2 * qb>() * alpha);
-                f1_vsetf<ST + 2 * qb + 1>(f1_vget<ST + 2 * qb + 1>() * alpha);
+                f1_vsetf<QBS, ST_MB + qb>(m_new == -INFINITY ? 0.0f : m_new * kLog2e);      // a row with no visible key yet keeps p = 0
+                f1_vsetf<QBS, ST_TH + qb>((m_new + kF1RescaleThr) * inv_scale);
+                f1_vsetf<QBS, ST + 2 * qb>(f1_vget<ST + 2 * qb>() * alpha);
+                f1_vsetf<QBS, ST + 2 * qb + 1>(f1_vget<ST + 2 * qb + 1>() * alpha);
                 pend[qb] = sc ? alpha : 1.0f;
                 any_scale = any_scale || sc;
             });
@@ -303,17 +375,17 @@ __global__ void __launch_bounds__(64 * kF1Waves, 1) __attribute__((amdgpu_num_vg
                 bool masked = key0 + 32 > Nk;
                 if (CAUSAL) masked = masked || key0 + 31 > q0 + p.causal_shift;
                 if (masked) {
-                    int hi[2];
+                    int hi[2] = {0, 0};
 #pragma unroll
-                    for (int qb = 0; qb < 2; ++qb) hi[qb] = (CAUSAL ? min(Nk, qrow[qb] + p.causal_shift + 1) : Nk) - key0 - 4 * h;
-                    f1_body<D, B, kb, true>(c2, need, hi, dma);
+                    for (int qb = 0; qb < QBS; ++qb) hi[qb] = (CAUSAL ? min(Nk, qrow[qb] + p.causal_shift + 1) : Nk) - key0 - 4 * h;
+                    f1_body<D, QBS, B, kb, true>(c2, need, hi, dma);
                 } else {
                     const int hi[2] = {0, 0};
-                    f1_body<D, B, kb, false>(c2, need, hi, dma);
+                    f1_body<D, QBS, B, kb, false>(c2, need, hi, dma);
                 }
             } else {
                 const int hi[2] = {0, 0};
-                f1_body<D, B, kb, false>(c2, need, hi, dma);
+                f1_body<D, QBS, B, kb, false>(c2, need, hi, dma);
             }
             // (both are SGPR values already; the readfirstlane tells hipcc that the branch is uniform)
             if (__builtin_amdgcn_readfirstlane(need | (int)have_pend)) update(need);
@@ -345,7 +417,7 @@ __global__ void __launch_bounds__(64 * kF1Waves, 1) __attribute__((amdgpu_num_vg
     // ---- epilogue
     mfma_acc_settle();
     const bool fin = !STATE || p.finalize;
-    static_for<2>([&](auto QB) {
+    static_for<QBS>([&](auto QB) {
         constexpr int qb = decltype(QB)::value;
         const float l_tot = half_sum(f1_vget<ST + 2 * qb>() + f1_vget<ST + 2 * qb + 1>());
         const size_t qoff = (size_t)head * qhs + qrow[qb];
@@ -357,8 +429,8 @@ __global__ void __launch_bounds__(64 * kF1Waves, 1) __attribute__((amdgpu_num_vg
             constexpr int dt = decltype(G)::value / 2, gp = decltype(G)::value % 2;
             constexpr int R = A_O + (qb * DT + dt) * 16 + 8 * gp;
             f32x4 v, w;
-            v[0] = acc_read<R>() * inv; v[1] = acc_read<R + 1>() * inv; v[2] = acc_read<R + 2>() * inv; v[3] = acc_read<R + 3>() * inv;
-            w[0] = acc_read<R + 4>() * inv; w[1] = acc_read<R + 5>() * inv; w[2] = acc_read<R + 6>() * inv; w[3] = acc_read<R + 7>() * inv;
+            v[0] = f1_aread<R>() * inv; v[1] = f1_aread<R + 1>() * inv; v[2] = f1_aread<R + 2>() * inv; v[3] = f1_aread<R + 3>() * inv;
+            w[0] = f1_aread<R + 4>() * inv; w[1] = f1_aread<R + 5>() * inv; w[2] = f1_aread<R + 6>() * inv; w[3] = f1_aread<R + 7>() * inv;
             if (fin) {
                 bf16x4 x, y;
 #pragma unroll
@@ -384,19 +456,42 @@ __global__ void __launch_bounds__(64 * kF1Waves, 1) __attribute__((amdgpu_num_vg
     });
 }
 
+// the two shapes as kernels: the register budgets differ (one wave per SIMD: hipcc keeps to v0..v63 of 512 registers; two waves
+// per SIMD: to v0..v39 of 128 + 128)
+template <int D, bool CAUSAL, bool STATE>
+__global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(64))) fa2_fwd1_bf16_kernel(FwdArgs p)
+{
+    fa2_fwd1_impl<D, 2, CAUSAL, STATE>(p);
+}
+template <int D, bool CAUSAL, bool STATE>
+__global__ void __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(40))) fa2_fwd1x2_bf16_kernel(FwdArgs p)
+{
+    fa2_fwd1_impl<D, 1, CAUSAL, STATE>(p);
+}
+
+#ifndef FA2_FWD64_QBS
+#define FA2_FWD64_QBS 1          // d = 64: 1 = two waves per SIMD (VALU-bound shape), 2 = one wave per SIMD
+#endif
+
 template <int D, bool CAUSAL, bool STATE>
 static hipError_t launch_one1(const FwdArgs& a, hipStream_t stream)
 {
     constexpr int lds = 2 * kF1Bufs * 16384;
-    auto kern = fa2_fwd1_bf16_kernel<D, CAUSAL, STATE>;
-    static bool attr_set[64] = {};
-    hipError_t e = ensure_dynamic_lds(kern, lds, attr_set);
-    if (e != hipSuccess) return e;
     const int nrb = (a.Nq + kF1Rows - 1) / kF1Rows;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(nrb * a.BH)), dim3(64 * kF1Waves), lds, stream, a);
+    static bool attr_set[64] = {};
+    if constexpr (D == 64 && FA2_FWD64_QBS == 1) {
+        auto kern = fa2_fwd1x2_bf16_kernel<D, CAUSAL, STATE>;
+        hipError_t e = ensure_dynamic_lds(kern, lds, attr_set);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(nrb * a.BH)), dim3(512), lds, stream, a);
+    } else {
+        auto kern = fa2_fwd1_bf16_kernel<D, CAUSAL, STATE>;
+        hipError_t e = ensure_dynamic_lds(kern, lds, attr_set);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(nrb * a.BH)), dim3(256), lds, stream, a);
+    }
     return hipGetLastError();
 }
-
 hipError_t launch_fwd1_bf16(const FwdArgs& a, hipStream_t stream)
 {
     const bool state = a.resume || !a.finalize;

@@ -127,30 +127,36 @@ def test_named_vgprs_are_the_bodies_own(asm, pattern, limit, top128, top64):
 
 
 def test_generated_forward_kernel(asm):
-    """fa2_fwd1_bf16_kernel (what fa2_forward runs for bf16) is compiled with amdgpu_num_vgpr(64): v64.. belong to the bodies
-    of tools/gen_fwd_body.py.  Per ring buffer and key block of a tile there is a plain and a masked body with 2 KS + 4 DT
-    MFMAs each; the bodies of a tile's last key block open with vmcnt(0) + s_barrier and carry the 8 LDS-DMA pieces of the
-    tile two ahead; nothing outside the asm regions names a body register."""
-    ks = {n: k for n, k in _kernels(asm["fa2_fwd1_bf16"]).items() if "fa2_fwd1_bf16_kernel" in n}
-    assert len(ks) == 8
+    """What fa2_forward runs for bf16 (csrc/fa2_fwd1_bf16.hip, bodies from tools/gen_fwd_body.py), in its two shapes:
+    fa2_fwd1_bf16_kernel -- one wave per SIMD, 64 rows per wave, amdgpu_num_vgpr(64), 512 registers -- and
+    fa2_fwd1x2_bf16_kernel -- two waves per SIMD, 32 rows per wave, amdgpu_num_vgpr(40), 128 + 128 registers (d = 64).
+    Per ring buffer and key block of a tile there is a plain and a masked body with QBS (KS + 2 DT) MFMAs; the bodies of a
+    tile's last key block open with vmcnt(0) + s_barrier and carry the LDS-DMA pieces of the tile two ahead (32 per
+    workgroup and tile); nothing outside the asm regions names a body register."""
+    ks = {n: k for n, k in _kernels(asm["fa2_fwd1_bf16"]).items() if "fa2_fwd1" in n and "bf16_kernel" in n}
+    assert len(ks) == 8           # d = 128 in the one-wave shape, d = 64 in the two-wave shape, each x causal x state
     pat = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
     for name, k in ks.items():
         D = 128 if "ILi128E" in name else 64
-        nh, per_body = (2, 32) if D == 128 else (4, 16)
+        qbs = 1 if "fwd1x2" in name else 2
+        nh = 2 if D == 128 else 4
+        per_body = qbs * (D // 16 + 2 * (D // 32))
+        own = 64 if qbs == 2 else 40
         outside, blocks = _split_asm(k["body"])
         for s in outside:
             for m in pat.finditer(s):
                 hi = int(m.group(1)) if m.group(1) else int(m.group(3))
-                assert hi < 64, (name, s)
-        assert k["meta"]["total"] == 512 and k["meta"]["scratch"] == 0 and k["meta"]["vgpr_spill"] == 0, (name, k["meta"])
-        bodies = [b for b in blocks if sum("v_mfma_f32_32x32x16_bf16" in s for s in b) == per_body]
+                assert hi < own, (name, s)
+        assert k["meta"]["scratch"] == 0 and k["meta"]["vgpr_spill"] == 0, (name, k["meta"])
+        assert k["meta"]["total"] == (512 if qbs == 2 else 256), (name, k["meta"])
+        bodies = [b for b in blocks if sum("v_mfma_f32_32x32x16_bf16" in s for s in b) == per_body and len(b) > 4 * per_body]
         # the loop over whole unmasked rounds holds 4 nh plain bodies; the general loop 4 nh plain + 4 nh masked
         assert len(bodies) == 12 * nh, (name, len(bodies))
         with_barrier = [b for b in bodies if any(s.startswith("s_barrier") for s in b)]
         assert len(with_barrier) == 12            # one per tile
         for b in with_barrier:
             assert b[0].startswith("s_waitcnt vmcnt(0)") and b[1].startswith("s_barrier")
-            assert sum(s.startswith("buffer_load_dwordx4") and s.endswith(" lds") for s in b) == 8
+            assert sum(s.startswith("buffer_load_dwordx4") and s.endswith(" lds") for s in b) == 32 // (8 // qbs)
         for b in bodies:
             if b not in with_barrier:
                 assert not any("buffer_load" in s for s in b)
@@ -254,7 +260,7 @@ def test_generated_bodies_pass_the_static_checker(inc):
     spec.loader.exec_module(cb)
     text = open(os.path.join(CSRC, inc)).read()
     names = re.findall(r"#define (FA2_\w+_[CM]?BODY_\w+) ", text)
-    assert len(names) in (12, 16, 18, 48)
+    assert len(names) in (12, 16, 18, 80)
     for n in names:
         assert cb.check(cb.body(text, n), n) == []
 

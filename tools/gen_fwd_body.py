@@ -45,10 +45,9 @@ from gen_dkdv_body import Task, COST
 
 READ_AHEAD = int(os.environ.get("FA2_GEN_READ_AHEAD", str(base.READ_AHEAD)))
 READ_LATEST = int(os.environ.get("FA2_GEN_READ_LATEST", str(base.READ_LATEST)))
-NSLOT = 8
 NBUF = 4
-A_O, A_QF = 0, 128
-V0 = 64
+# (head_dim, row blocks per wave): what fa2_fwd1_bf16.hip instantiates
+CONFIGS = ((128, 2), (64, 2), (64, 1))
 COST = dict(COST, vmem=12, cmp=8)
 NEG_INF = "0xff800000"
 
@@ -58,18 +57,27 @@ def kv_of(D):
 
 
 class Regs:
-    def __init__(self, D):
-        self.D, self.KS, self.DT = D, D // 16, D // 32
+    """Register map for head_dim D and QBS row blocks per wave.  QBS = 2: one wave per SIMD (512 registers, hipcc owns v0..v63);
+    QBS = 1: two waves per SIMD (128 + 128 registers, hipcc owns v0..v39)."""
+
+    def __init__(self, D, QBS):
+        self.D, self.KS, self.DT, self.QBS = D, D // 16, D // 32, QBS
         self.KV = kv_of(D)
         self.NH = self.KV // 32
-        self.SET = [V0, V0 + 32]
-        self.PF = [V0 + 64, V0 + 80]
-        self.SLOT = V0 + 96
-        self.ROFF = self.SLOT + 4 * NSLOT
+        self.WAVES = 8 // QBS
+        self.NSLOT = 8 if QBS == 2 else 6
+        self.V0 = V0 = 64 if QBS == 2 else 40
+        self.A_O = 0
+        self.A_QF = 16 * QBS * self.DT
+        self.SET = [V0, V0 + 16 * QBS]
+        self.PF = [V0 + 32 * QBS, V0 + 40 * QBS]
+        self.SLOT = V0 + 48 * QBS
+        self.ROFF = self.SLOT + 4 * self.NSLOT
         self.TOFFV = self.ROFF + self.KS
-        self.STATE = self.TOFFV + 2 * self.DT      # l0a l0b l1a l1b | rm0 rm1 | mb0 mb1 | th0 th1
-        self.VEND = self.STATE + 10
-        assert self.VEND <= 256
+        self.STATE = self.TOFFV + 2 * self.DT      # l (2 per row block) | rm | mb | th (1 per row block each)
+        self.VEND = self.STATE + 5 * QBS
+        assert self.VEND <= (256 if QBS == 2 else 128), self.VEND
+        assert self.A_QF + 4 * QBS * self.KS <= (256 if QBS == 2 else 128)
 
     def s(self, par, qb): b = self.SET[par] + 16 * qb; return f"v[{b}:{b + 15}]"
     def sreg(self, par, qb, r): return f"v{self.SET[par] + 16 * qb + r}"
@@ -81,21 +89,22 @@ class Regs:
     def roff(self, s): return f"v{self.ROFF + s}"
     def toffv(self, i): return f"v{self.TOFFV + i}"
     def l(self, qb, e): return f"v{self.STATE + 2 * qb + e}"
-    def rm(self, qb): return f"v{self.STATE + 4 + qb}"
-    def mb(self, qb): return f"v{self.STATE + 6 + qb}"
-    def th(self, qb): return f"v{self.STATE + 8 + qb}"
-    def qf(self, qb, s): b = A_QF + 4 * (qb * self.KS + s); return f"a[{b}:{b + 3}]"
-    def o(self, qb, dt): b = A_O + 16 * (qb * self.DT + dt); return f"a[{b}:{b + 15}]"
+    def rm(self, qb): return f"v{self.STATE + 2 * self.QBS + qb}"
+    def mb(self, qb): return f"v{self.STATE + 3 * self.QBS + qb}"
+    def th(self, qb): return f"v{self.STATE + 4 * self.QBS + qb}"
+    def qf(self, qb, s): b = self.A_QF + 4 * (qb * self.KS + s); return f"a[{b}:{b + 3}]"
+    def o(self, qb, dt): b = self.A_O + 16 * (qb * self.DT + dt); return f"a[{b}:{b + 15}]"
 
 
-def build(D, par, masked, dma):
+def build(D, QBS, par, masked, dma):
     """One body for a key block of parity `par` (S set / PF set selection).  Gap units 0 .. NS-1; tasks with a negative
     release belong to the tail of the previous body (they are emitted there with the NEXT body's bases: '@N')."""
-    R = Regs(D)
-    KS, DT = R.KS, R.DT
+    R = Regs(D, QBS)
+    KS, DT, NSLOT = R.KS, R.DT, R.NSLOT
     ROWB = 2 * D
-    NS = 2 * KS + 4 * DT
-    gP = 2 * KS
+    NS = QBS * (KS + 2 * DT)
+    gP = QBS * KS
+    QB = range(QBS)
     mfma = [None] * NS
     tasks = []
     ctr = [0]
@@ -114,24 +123,24 @@ def build(D, par, masked, dma):
 
     def allocate(rec):
         for s in range(KS):
-            g = 2 * s
-            sk, fk = take(g + 1)
+            g = QBS * s
+            sk, fk = take(g + QBS - 1)
             if rec:
                 key = ("K", s)
                 rd(f"ds_read_b128 {R.slot(sk)}, {R.roff(s)} offset:@K+0", key, g, fk)
-                for qb in (0, 1):
+                for qb in QB:
                     c = "0" if s == 0 else R.s(par, qb)
                     mfma[g + qb] = (f"v_mfma_f32_32x32x16_bf16 {R.s(par, qb)}, {R.slot(sk)}, {R.qf(qb, s)}, {c}", [key])
         for sp in (0, 1):
             for dt in range(DT):
-                g = gP + 2 * (sp * DT + dt)
-                sv, fv = take(g + 1)
+                g = gP + QBS * (sp * DT + dt)
+                sv, fv = take(g + QBS - 1)
                 if rec:
                     ka, kb_ = ("VT", sp, dt, 0), ("VT", sp, dt, 1)
                     off = sp * 16 * ROWB
                     rd(f"ds_read_b64_tr_b16 {R.slot_lo(sv)}, {R.toffv(2 * dt)} offset:@VP+{off}", ka, g, fv)
                     rd(f"ds_read_b64_tr_b16 {R.slot_hi(sv)}, {R.toffv(2 * dt + 1)} offset:@VP+{off}", kb_, g, fv)
-                    for qb in (0, 1):
+                    for qb in QB:
                         # P of block j - 2: the same parity as this block's
                         mfma[g + qb] = (f"v_mfma_f32_32x32x16_bf16 {R.o(qb, dt)}, {R.slot(sv)}, {R.pf(par, qb, sp)}, {R.o(qb, dt)}", [ka, kb_])
 
@@ -155,10 +164,10 @@ def build(D, par, masked, dma):
     #      MFMAs, so the 16 element pairs of a body may go anywhere in it: they are given staggered windows (pair k around gap
     #      k NS / 16) so that every gap carries the same mix -- one exponential or two, never a burst of them.
     op = par ^ 1
-    span = NS / 16.0
+    span = NS / (8.0 * QBS)
     k = 0
     for sp in (0, 1):
-        for qb in (0, 1):
+        for qb in QB:
             for j in range(4):
                 c = int(k * span)
                 rel, dl = max(0, c - int(span)), min(NS - 1, c + int(span) + 2)
@@ -174,8 +183,8 @@ def build(D, par, masked, dma):
 
     # ---- lane maxima of block j behind its A chains (masked variant: dead keys to -inf first), then the compare
     last = []
-    for qb in (0, 1):
-        rel = 2 * (KS - 1) + qb + 3          # the chain's last product has left the matrix pipe
+    for qb in QB:
+        rel = min(QBS * (KS - 1) + qb + 3, NS - 3)          # the chain's last product has left the matrix pipe
         prev = None
         masks = {}
         if masked:
@@ -189,37 +198,41 @@ def build(D, par, masked, dma):
             dep = ([prev] if prev else []) + ([masks[2 * i], masks[2 * i + 1]] if masked else [])
             prev = valu(text, "valu", rel, NS - 2, after=dep)
         last.append(prev)
-    valu(f"v_cmp_gt_f32 vcc, {R.rm(0)}, {R.th(0)}\n\tv_cmp_gt_f32 s[10:11], {R.rm(1)}, {R.th(1)}\n\ts_or_b64 vcc, vcc, s[10:11]\n\t"
-         "s_or_b32 %[need], vcc_lo, vcc_hi", "cmp", NS - 2, NS - 1, after=last)
+    if QBS == 2:
+        valu(f"v_cmp_gt_f32 vcc, {R.rm(0)}, {R.th(0)}\n\tv_cmp_gt_f32 s[10:11], {R.rm(1)}, {R.th(1)}\n\ts_or_b64 vcc, vcc, s[10:11]\n\t"
+             "s_or_b32 %[need], vcc_lo, vcc_hi", "cmp", NS - 2, NS - 1, after=last)
+    else:
+        valu(f"v_cmp_gt_f32 vcc, {R.rm(0)}, {R.th(0)}\n\ts_or_b32 %[need], vcc_lo, vcc_hi", "cmp", NS - 2, NS - 1, after=last)
 
     # ---- LDS-DMA of tile t + 2 (bodies of a tile's last key block only): piece i of tensor `which` for this wave
     if dma:
         TILEB = R.KV * ROWB
-        npw = TILEB // 1024 // 4                 # pieces per tensor per wave
+        npw = TILEB // 1024 // R.WAVES           # pieces per tensor per wave
+        step = R.WAVES                           # a wave's pieces are `step` apart
         rpi = 1024 // ROWB                       # rows per piece
         for which in (0, 1):
             for i in range(npw):
                 rs = "%[vrs]" if which else "%[krs]"
-                so = f"s_add_u32 s12, %[kso], {4 * i * rpi * ROWB}" if i else "s_nop 0"
+                so = f"s_add_u32 s12, %[kso], {step * i * rpi * ROWB}" if i else "s_nop 0"
                 n = which * npw + i                  # one piece every NS / (2 npw + 1) gaps, not a burst of them
-                g0 = 1 + int(n * (NS - 4) / (2 * npw))
-                tasks.append(Task(f"s_add_u32 m0, %[mw], @NB+{which * NBUF * TILEB + 4 * i * 1024}\n\t{so}\n\t"
+                g0 = 1 + int(n * max(NS - 4, 1) / (2 * npw))
+                tasks.append(Task(f"s_add_u32 m0, %[mw], @NB+{which * NBUF * TILEB + step * i * 1024}\n\t{so}\n\t"
                                   f"buffer_load_dwordx4 %[dvo], {rs}, {'s12' if i else '%[kso]'} offen lds", COST["vmem"], g0, g0 + 3, "vmem",
                                   ("dma", which, i)))
     return R, mfma, tasks, NS
 
 
-def render(D, par, masked, dma, budget):
-    R, mfma, tasks, NS = build(D, par, masked, dma)
+def render(D, QBS, par, masked, dma, budget):
+    R, mfma, tasks, NS = build(D, QBS, par, masked, dma)
     per_gap, load = base.place(tasks, NS, budget)
     lines, pro = base.render_lines(mfma, per_gap, NS)
     return R, lines, pro, load, NS
 
 
-def resolve(lines, D, buf, kb, barrier):
+def resolve(lines, D, QBS, buf, kb, barrier):
     """Substitutes the placeholders for the body of key block kb of the tile in ring buffer buf; '@N ' lines (the next
     body's early reads) get the next key block's bases."""
-    R = Regs(D)
+    R = Regs(D, QBS)
     ROWB = 2 * D
     TILEB = R.KV * ROWB
     lines = [part for l in lines for part in (l.split("\n\t") if not l.startswith("@N ") else [l])]
@@ -252,30 +265,32 @@ def main():
     chunks = ["// GENERATED by tools/gen_fwd_body.py -- do not edit.  Main-loop bodies of fa2_fwd1_bf16_kernel (one wave per SIMD):\n"
               "// FA2_FWD_BODY_D<d>_B<ring buffer>_K<key block of the tile>_M<masked> and the prologue FA2_FWD_PRO_D<d> (the early reads\n"
               "// of the very first body).  Register map, LDS map and schedule: the generator.\n"]
-    for D in (128, 64):
-        R0 = Regs(D)
+    for D, QBS in CONFIGS:
+        R0 = Regs(D, QBS)
+        tag = f"D{D}Q{QBS}"
         budget = int(os.environ.get("FA2_GEN_BUDGET_FWD%d" % D, "24" if D == 128 else "44"))
-        chunks.append(f"#define FA2_FWD_D{D}_SET0 {R0.SET[0]}\n#define FA2_FWD_D{D}_SET1 {R0.SET[1]}\n#define FA2_FWD_D{D}_PF0 {R0.PF[0]}\n"
-                      f"#define FA2_FWD_D{D}_ROFF {R0.ROFF}\n#define FA2_FWD_D{D}_TOFFV {R0.TOFFV}\n#define FA2_FWD_D{D}_VEND {R0.VEND}\n"
-                      f"#define FA2_FWD_D{D}_KV {R0.KV}\n#define FA2_FWD_D{D}_STATE {R0.STATE}\n")
+        chunks.append(f"#define FA2_FWD_{tag}_SET0 {R0.SET[0]}\n#define FA2_FWD_{tag}_SET1 {R0.SET[1]}\n#define FA2_FWD_{tag}_PF0 {R0.PF[0]}\n"
+                      f"#define FA2_FWD_{tag}_ROFF {R0.ROFF}\n#define FA2_FWD_{tag}_TOFFV {R0.TOFFV}\n#define FA2_FWD_{tag}_VEND {R0.VEND}\n"
+                      f"#define FA2_FWD_{tag}_KV {R0.KV}\n#define FA2_FWD_{tag}_STATE {R0.STATE}\n#define FA2_FWD_{tag}_V0 {R0.V0}\n"
+                      f"#define FA2_FWD_{tag}_A_QF {R0.A_QF}\n")
         pros = set()
         for masked in (0, 1):
             for kb in range(R0.NH):
                 par = kb & 1
                 dma = kb == R0.NH - 1
-                R, lines, pro, load, NS = render(D, par, bool(masked), dma, budget + (12 if masked else 0) + (4 if dma else 0))
+                R, lines, pro, load, NS = render(D, QBS, par, bool(masked), dma, budget + (12 if masked else 0) + (4 if dma else 0))
                 pros.add(tuple(pro))
                 if args.check:
-                    print(f"D={D} kb={kb} masked={masked} dma={int(dma)}: {len(lines)} lines, {sum('v_mfma' in l for l in lines)} MFMAs, "
+                    print(f"{tag} kb={kb} masked={masked} dma={int(dma)}: {len(lines)} lines, {sum('v_mfma' in l for l in lines)} MFMAs, "
                           f"{len(pro)} early, max gap load {max(load)}, mean {sum(load) / len(load):.1f}")
                     print("   load:", " ".join(str(l) for l in load))
                 for buf in range(NBUF):
-                    body = resolve(lines, D, buf, kb, dma)
-                    chunks.append(f"#define FA2_FWD_BODY_D{D}_B{buf}_K{kb}_M{masked} \\\n" + base.c_string(body) + "\n")
+                    body = resolve(lines, D, QBS, buf, kb, dma)
+                    chunks.append(f"#define FA2_FWD_BODY_{tag}_B{buf}_K{kb}_M{masked} \\\n" + base.c_string(body) + "\n")
         assert len(pros) == 1, "every body must leave the same reads in flight for the next one"
-        p = resolve(list(pros.pop()), D, NBUF - 1, R0.NH - 1, False)       # 'next' of the last key block of buffer 3 = (buffer 0, kb 0)
+        p = resolve(list(pros.pop()), D, QBS, NBUF - 1, R0.NH - 1, False)       # 'next' of the last key block of buffer 3 = (buffer 0, kb 0)
         p.append("s_waitcnt lgkmcnt(0)")
-        chunks.append(f"#define FA2_FWD_PRO_D{D} \\\n" + base.c_string(p) + "\n")
+        chunks.append(f"#define FA2_FWD_PRO_{tag} \\\n" + base.c_string(p) + "\n")
     if not args.check:
         with open(args.out, "w") as f:
             f.write("\n".join(chunks))
