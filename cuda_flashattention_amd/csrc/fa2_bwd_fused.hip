@@ -379,10 +379,33 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
 #endif
 
         const auto null_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)fp.dQacc, 0, 0, 0x00020000);     // every access out of range
-        auto step = [&](auto BUF, auto PAR, auto MASKED, int t) {
+        // FAST: a step in the middle of a unit (1 <= t, t + 1 < n_u, and for the causal form the previous key block exists for
+        // sub-tile tl(t)): every selection below is decided, what is left between two bodies is a handful of scalar adds.
+        // The general form costs ~25 scalar instructions per body (3 % of it: one wave per SIMD, nothing hides them).
+        const bool hp_unit = CAUSAL ? true : cb > 0;
+        const auto lrs_unit = hp_unit && !(FA2_FUSED_DIAG & 2) ? dq_rsrc : null_rsrc;
+        auto step = [&](auto BUF, auto PAR, auto MASKED, auto FAST_, int t) {
             constexpr int buf = decltype(BUF)::value, par = decltype(PAR)::value;
             constexpr bool masked = decltype(MASKED)::value;
-            if constexpr (CHAIN) {
+            constexpr bool FAST = decltype(FAST_)::value;
+            if constexpr (CHAIN && FAST) {
+                FusedStep f;
+                f.drs = dq_rsrc;
+                f.lrs = lrs_unit;
+                f.dso = (uint32_t)(tl(t - 1) * TROWS * D * 4);
+                f.lso = (uint32_t)(tl(t) * TROWS * D * 4);
+                f.qrs = q_rsrc; f.grs = g_rsrc; f.rcrs = rc_rsrc; f.ctl = ctl_rsrc;
+                f.qso = (uint32_t)(tl(t + 1) * TROWS * ROWB + wave * 1024);
+                f.rcso = (uint32_t)(tl(t + 1) * TROWS * 4);
+                f.pvo = (uint32_t)prev_off; f.mso = (uint32_t)mine_off;
+                f.need = (hp_unit && !err && !(FA2_FUSED_DIAG & 1)) ? t + 1 : (int)0x80000000;
+                f.pval = t;
+#ifdef FA2_TEST_HOOKS
+                if (fp.fault && cb == 1) f.pval = 0;
+#endif
+                fused_cbody<buf, par, VMW, false>(roff, toff, rcv, c2, dqv, (uint32_t)doff, (uint32_t)rcoff, lbase + QRING + wave * 1024,
+                                                  lbase + QRING + wave * 128, wave, f, err, 0, 0);
+            } else if constexpr (CHAIN) {
                 // body of step t: DMA of the sub-tile of step t + 1; E forms the dQ tile of the sub-tile of step t - 1 on top of
                 // the running sum loaded by body t - 1 and stores it; behind the barrier it publishes "t sub-tiles out", waits
                 // until the previous key block of the chain has published t + 1, and loads the running sum for step t
@@ -427,22 +450,30 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
                 fused_dq_zero<DQT>();
             }
         };
-        auto six = [&](auto MASKED, int t) {
-            step(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, MASKED, t);
-            step(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, MASKED, t + 1);
-            step(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, MASKED, t + 2);
-            step(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, MASKED, t + 3);
-            step(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, MASKED, t + 4);
-            step(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, MASKED, t + 5);
+        auto six = [&](auto MASKED, auto FAST_, int t) {
+            step(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, MASKED, FAST_, t);
+            step(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, MASKED, FAST_, t + 1);
+            step(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, MASKED, FAST_, t + 2);
+            step(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, MASKED, FAST_, t + 3);
+            step(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, MASKED, FAST_, t + 4);
+            step(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, MASKED, FAST_, t + 5);
         };
-        if constexpr (!CAUSAL) {
+        // sixes whose every step is FAST: t >= 6 (so t >= 1), t + 5 + 1 < n_u, and for the causal form tl(t + 5) >= 8 cb + 8,
+        // i.e. t + 5 <= n_u - 9 (which also keeps them in front of the masked bodies)
+        const int fast_end = CHAIN ? (CAUSAL ? n_u - 9 : n_u - 2) : -1;       // last step that may be FAST
+        {
+            const int plain_end = CAUSAL ? first_masked : niter_u;
+            int t = 0;
+            asm volatile("" : "+s"(t));          // not a literal: the bodies take values derived from it in SGPR operands
+            if (t < plain_end) { six(std::false_type{}, std::false_type{}, t); t += 6; }
 #pragma unroll 1
-            for (int t = 0; t < niter_u; t += 6) six(std::false_type{}, t);
-        } else {
+            for (; t + 5 <= fast_end && t < plain_end; t += 6) six(std::false_type{}, std::true_type{}, t);
 #pragma unroll 1
-            for (int t = 0; t < first_masked; t += 6) six(std::false_type{}, t);
+            for (; t < plain_end; t += 6) six(std::false_type{}, std::false_type{}, t);
+            if constexpr (CAUSAL) {
 #pragma unroll 1
-            for (int t = first_masked; t < niter_u; t += 6) six(std::true_type{}, t);
+                for (; t < niter_u; t += 6) six(std::true_type{}, std::false_type{}, t);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         if constexpr (CHAIN)

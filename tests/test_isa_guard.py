@@ -165,9 +165,11 @@ def test_generated_forward_kernel(asm):
 
 def test_fused_backward_kernel(asm):
     """The single-kernel backward is compiled with amdgpu_num_vgpr(39): v39 (progress-word prefetch) and v40..v255 belong to
-    the generated body (tools/gen_fused_body.py).  Its hot loop holds six bodies of 80 MFMAs (ring of three Q/dO
-    buffers x two dS tiles), the chained form's bodies carry their four dQ stores in front of the barrier and the four
-    running-sum loads behind it, and nothing in the loop touches scratch."""
+    the generated body (tools/gen_fused_body.py).  A unit's steps run in three loops of six bodies of 80 MFMAs (ring of three
+    Q/dO buffers x two dS tiles): the first six steps, the steady-state sixes (every per-step selection decided: ~8 scalar
+    instructions between two bodies instead of ~25) and the last ones; the causal form adds a loop of six masked bodies.  The
+    chained form's bodies carry their four dQ stores in front of the barrier and the four running-sum loads behind it, and
+    nothing touches scratch."""
     ks = {n: k for n, k in _kernels(asm["fa2_bwd_fused"]).items() if "fa2_bwd_fused_kernelILb" in n}
     assert len(ks) == 3          # <atomics>, <chain>, <chain, causal>
     pat = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
@@ -179,13 +181,11 @@ def test_fused_backward_kernel(asm):
                 hi = int(m.group(1)) if m.group(1) else int(m.group(3))
                 assert hi < 39, (name, s)
         assert k["meta"]["total"] == 512 and k["meta"]["agpr"] == 256, (name, k["meta"])
-        if causal:       # two inner loops of six bodies (plain, masked) inside the unit loop, + the 16 accumulator-zeroing MFMAs
-            assert sum("v_mfma_f32_32x32x16_bf16" in l for l in k["body"]) == 12 * 80 + 16, name
-        else:
-            assert sum("v_mfma_f32_32x32x16_bf16" in l for l in _main_loop(k["body"])) == 6 * 80, name
+        nb = 24 if causal else 18      # six-body loops inside the unit loop: first, steady state, last (+ masked); + the 16 zeroing MFMAs
+        assert sum("v_mfma_f32_32x32x16_bf16" in l for l in k["body"]) == nb * 80 + 16, name
         assert not any("scratch_" in l for l in k["body"]), name
         bodies = [b for b in _split_asm(k["body"])[1] if sum("v_mfma" in s for s in b) == 80]
-        assert len(bodies) == (12 if causal else 6)          # causal: a second loop of six bodies that carry the mask
+        assert len(bodies) == nb
         assert sum(any(s.startswith("v_cmp_le_i32 vcc") for s in b) for b in bodies) == (6 if causal else 0)
         for b in bodies:
             st = [i for i, s in enumerate(b) if s.startswith("buffer_store_dwordx4")]
