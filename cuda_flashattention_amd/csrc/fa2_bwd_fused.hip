@@ -206,9 +206,12 @@ __device__ __forceinline__ bool fused_spin_over(int* ctl, int spins)
 //     the workgroup holding the oldest unfinished unit never waits: no deadlock for any number of resident workgroups.
 //   CAUSAL (chained form only, square, no shift): key block cb sees the query sub-tiles t >= 8 cb, the first eight of them
 //     through a mask.  Everything runs on the REVERSED sub-tile index: every key block starts at the last sub-tile and walks
-//     down to its diagonal, so all of a head's workgroups start at once; the sum of a sub-tile starts at the key block on
-//     whose diagonal it lies and is handed DOWN to key block 0, which holds every final sum.  Units are therefore taken
-//     in descending key-block order (a unit waits only for units taken before it), and the masked bodies are a unit's last.
+//     down to its diagonal, so all of a head's workgroups start at once and key block cb follows key block cb - 1 a step or
+//     two behind, exactly as in the non-causal form: the sum of a sub-tile starts at key block 0 and is handed UP to the key
+//     block on whose diagonal it lies, which stores the final sum.  Units are taken in ascending key-block order (a unit
+//     waits only for units taken before it) -- the longest first -- and the masked bodies are a unit's last.  (Round 2 handed
+//     the sums DOWN to key block 0 and had to take the longest units last: the last head of every XCD then ended with one
+//     workgroup walking 256 steps alone.)
 template <bool CHAIN, bool CAUSAL>
 __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) fa2_bwd_fused_kernel(FusedArgs fp)
 {
@@ -307,7 +310,6 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
             __syncthreads();
             head = __builtin_amdgcn_readfirstlane(mail[0]);
             cb = __builtin_amdgcn_readfirstlane(mail[1]);
-            if (CAUSAL) cb = ncb - 1 - cb;
             err0 = __builtin_amdgcn_readfirstlane(mail[2]);
             if (head < 0) break;
         } else {
@@ -368,7 +370,7 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
 
         const auto dq_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(fp.dQacc + (size_t)head * N * D), 0, N * D * 4, 0x00020000);
         int* const mine = prog_base + head * ncb + cb;
-        const int* const prev = mine + (CAUSAL ? 1 : -1);             // the key block this one takes the running sums from
+        const int* const prev = mine - 1;                             // the key block this one takes the running sums from
         const int prev_off = (int)((prev - fp.ctl) * 4);
         const int mine_off = (int)((mine - fp.ctl) * 4);
         if constexpr (CHAIN) fused_seen_set(0);          // what prev was last seen at
@@ -382,7 +384,7 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
         // FAST: a step in the middle of a unit (1 <= t, t + 1 < n_u, and for the causal form the previous key block exists for
         // sub-tile tl(t)): every selection below is decided, what is left between two bodies is a handful of scalar adds.
         // The general form costs ~25 scalar instructions per body (3 % of it: one wave per SIMD, nothing hides them).
-        const bool hp_unit = CAUSAL ? true : cb > 0;
+        const bool hp_unit = cb > 0;
         const auto lrs_unit = hp_unit && !(FA2_FUSED_DIAG & 2) ? dq_rsrc : null_rsrc;
         auto step = [&](auto BUF, auto PAR, auto MASKED, auto FAST_, int t) {
             constexpr int buf = decltype(BUF)::value, par = decltype(PAR)::value;
@@ -412,7 +414,7 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
                 FusedStep f;
                 const bool live = t >= 1 && t <= n_u;
                 const bool more = t + 1 < n_u;                                   // step t + 1 has a sub-tile (else: zero rows)
-                const bool has_prev = t < n_u && (CAUSAL ? tl(t) >= 8 * cb + 8 : cb > 0);
+                const bool has_prev = t < n_u && cb > 0;
                 f.drs = live ? dq_rsrc : null_rsrc;
                 f.lrs = has_prev && !(FA2_FUSED_DIAG & 2) ? dq_rsrc : null_rsrc;
                 f.dso = (uint32_t)__builtin_amdgcn_readfirstlane(tl(t - 1) * TROWS * D * 4);
@@ -458,9 +460,8 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
             step(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, MASKED, FAST_, t + 4);
             step(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, MASKED, FAST_, t + 5);
         };
-        // sixes whose every step is FAST: t >= 6 (so t >= 1), t + 5 + 1 < n_u, and for the causal form tl(t + 5) >= 8 cb + 8,
-        // i.e. t + 5 <= n_u - 9 (which also keeps them in front of the masked bodies)
-        const int fast_end = CHAIN ? (CAUSAL ? n_u - 9 : n_u - 2) : -1;       // last step that may be FAST
+        // sixes whose every step is FAST: t >= 6 (so t >= 1), t + 5 + 1 < n_u; the causal form's masked bodies come behind them
+        const int fast_end = CHAIN ? n_u - 2 : -1;                            // last step that may be FAST
         {
             const int plain_end = CAUSAL ? first_masked : niter_u;
             int t = 0;
