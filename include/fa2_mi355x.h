@@ -112,7 +112,11 @@ size_t fa2_backward_workspace_bytes(int B, int H, int seq_len, int head_dim, int
  *     (csrc/fa2_bwd_fused.hip); a workgroup owns 256 keys (dK, dV in registers) and the dQ tiles are summed key block
  *     after key block in a fixed order through the L2 of the XCD the head is pinned to;
  *   - everything else: a dQ kernel and a dK/dV kernel (seven products, csrc/fa2_bwd_bf16.hip).
- * The environment variable FA2_BACKWARD_PATH=two_kernel keeps every shape on the second form. */
+ * The environment variable FA2_BACKWARD_PATH=two_kernel keeps every shape on the second form.
+ * PLACEMENT ASSUMPTION of the first form: its workgroups read HW_REG_XCC_ID and hand running sums to each other through the
+ * L2 of that XCC (plain stores, sc1 loads); validated on gfx950 in SPX mode (one device = 8 XCCs x 32 CUs).  On any other
+ * device layout (a partitioned GPU, another architecture) this call runs the second form instead: fa2_backward_plan.
+ * A hand-off that times out (every wait is bounded) leaves dQ all NaN and dK / dV complete: fa2_backward_status. */
 int fa2_backward(const void* Q, const void* K, const void* V, const void* O, const float* L,
                  const void* dO, void* dQ, void* dK, void* dV,
                  int B, int H, int seq_len, int head_dim, float softmax_scale,

@@ -198,3 +198,23 @@ def test_fa1_baseline_matches_oracle_medium():
     assert lib.flash_attention(None, None, None, None, None, None, 4, 4, 32, 1024) == -1
     assert lib.flash_attention(dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), O.data_ptr(), l.data_ptr(), m.data_ptr(),
                                77, 5, 0, 1024) == -2          # Bc = 0
+
+
+def test_read_clocks_brackets_a_stretch_of_work():
+    """fa2_read_clocks: two 64-bit device counters (shader-clock ticks, 100 MHz reference ticks); two calls around some work
+    give a plausible mean shader clock (what bench.py's `sustained` object reports)."""
+    import cuda_flashattention_amd as fa
+    lib = fa._capi.lib()
+    clk = torch.zeros(4, dtype=torch.int64, device="cuda")
+    x = torch.rand(4096, 4096, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    assert lib.fa2_read_clocks(clk.data_ptr(), s) == 0
+    for _ in range(20):
+        x = x @ x * 1e-3
+    assert lib.fa2_read_clocks(clk.data_ptr() + 16, s) == 0
+    torch.cuda.synchronize()
+    c = clk.cpu().tolist()
+    assert c[2] > c[0] and c[3] > c[1]
+    mhz = (c[2] - c[0]) / (c[3] - c[1]) * 100.0
+    assert 300.0 < mhz < 3000.0, mhz
+    assert lib.fa2_read_clocks(None, s) == -1
