@@ -7,6 +7,7 @@
 //   mode 0  bare MFMAs
 //   mode 1  + one 1 KiB ds_read_b128 per unit, used as the A operand of a later unit
 //   mode 2  forward-like mix per unit: 1 ds_read_b128, 1 v_exp_f32, 3 plain VALU
+//   modes 4-6  bare MFMAs with operand reuse between consecutive MFMAs: A stationary / nothing shared / both shared
 //   mode 3  single-kernel-backward mix per 2 units (tools/isa_mix.py: 1.9 LDS, 1.2 VALU, 0.4 exp, 0.7 SALU,
 //           0.4 waits per 32x32x16): 4 ds_read_b64, 1 v_exp_f32, 2 VALU, 1 SALU, 1 counted wait
 // Prints, per variant: wall ms, shader clock (s_memtime ticks / wall), ticks per unit per SIMD, TFLOP/s.
@@ -44,6 +45,7 @@ __global__ void __launch_bounds__(THREADS) k(const bf16x8* in, float* out, long 
     for (int i = threadIdx.x; i < 4096; i += THREADS) ((bf16x8*)lds)[i] = in[(i * 7 + blockIdx.x) & 4095];
     __syncthreads();
     bf16x8 a0 = in[threadIdx.x], b0 = in[threadIdx.x + 512], a1 = in[threadIdx.x + 1024], b1 = in[threadIdx.x + 1536];
+    bf16x8 a2 = in[threadIdx.x + 2048], b2 = in[threadIdx.x + 2560], a3 = in[threadIdx.x + 3072], b3 = in[(threadIdx.x + 3584) & 4095];
     f32x16 c32[4] = {};
     f32x4 c16[8] = {};
     float x0 = 0.1f * threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3;
@@ -51,11 +53,20 @@ __global__ void __launch_bounds__(THREADS) k(const bf16x8* in, float* out, long 
     bf16x8 l0 = a0, l1 = a1;
     f32x2 h0, h1, h2, h3;
     h0[0] = h0[1] = h1[0] = h1[1] = h2[0] = h2[1] = h3[0] = h3[1] = 0.f;
-    asm volatile("" :: "v"(a0), "v"(b0), "v"(a1), "v"(b1));   // operands landed before the loop: no vmcnt wait inside it
+    asm volatile("" :: "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3));   // operands landed before the loop: no vmcnt wait inside it
     long long t0 = __builtin_amdgcn_s_memtime();
     for (int i = 0; i < iters; ++i) {
         if constexpr (MODE == 0) {
             UNIT(0, a0, b0, NONE, NONE); UNIT(1, a1, b1, NONE, NONE); UNIT(2, a0, b1, NONE, NONE); UNIT(3, a1, b0, NONE, NONE);
+        }
+        if constexpr (MODE == 4) {      // operand-stationary order: consecutive MFMAs share their A operand (4 in a row), then B changes
+            UNIT(0, a0, b0, NONE, NONE); UNIT(1, a0, b1, NONE, NONE); UNIT(2, a0, b2, NONE, NONE); UNIT(3, a0, b3, NONE, NONE);
+        }
+        if constexpr (MODE == 5) {      // every MFMA with both operands different from the previous one's (8 fragments in rotation)
+            UNIT(0, a0, b0, NONE, NONE); UNIT(1, a1, b1, NONE, NONE); UNIT(2, a2, b2, NONE, NONE); UNIT(3, a3, b3, NONE, NONE);
+        }
+        if constexpr (MODE == 6) {      // both operands the same for 4 MFMAs in a row (4 accumulators)
+            UNIT(0, a0, b0, NONE, NONE); UNIT(1, a0, b0, NONE, NONE); UNIT(2, a0, b0, NONE, NONE); UNIT(3, a0, b0, NONE, NONE);
         }
         if constexpr (MODE == 1) {
             UNIT(0, a0, b0, LDS128(l0, la, 0), NONE); UNIT(1, a1, b1, NONE, LDS128(l1, la, 1024));
@@ -128,6 +139,9 @@ int main(int argc, char** argv)
     for (int rep = 0; rep < 2; ++rep) {     // twice: the second table is the warmed-up one
         printf("--- pass %d\n", rep);
         both<0>("bare", in, out, cyc, iters);
+        both<6>("bare, same A and B four times in a row", in, out, cyc, iters);
+        both<4>("bare, A stationary over four MFMAs", in, out, cyc, iters);
+        both<5>("bare, A and B change every MFMA", in, out, cyc, iters);
         both<1>("+1 KiB ds_read_b128 per unit", in, out, cyc, iters);
         both<2>("+b128, exp, 3 VALU per unit (forward mix)", in, out, cyc, iters);
         both<3>("+4 b64, exp, 2 VALU, SALU, wait per 2 units", in, out, cyc, iters);
