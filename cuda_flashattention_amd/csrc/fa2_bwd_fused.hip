@@ -632,7 +632,11 @@ hipError_t launch_bwd_fused_bf16(const BwdArgs& a, float* dQacc, int* ctl, int m
         e = hipMemsetAsync(ctl, 0, bwd_fused_ctl_bytes(a.BH, a.Nk), stream);
         if (e != hipSuccess) return e;
         static bool set_t[64] = {}, set_c[64] = {};
-        int wgs = units < cus[dev] ? units : cus[dev];
+        // a.reserve_cus: the ring backward's exchanges (RCCL kernels on the communication stream) must find a CU while this
+        // grid runs -- its workgroups are persistent and fill a CU's register file, nothing else becomes resident beside them
+        int avail = cus[dev] - (a.reserve_cus > 0 ? a.reserve_cus : 0);
+        if (avail < 1) avail = 1;
+        int wgs = units < avail ? units : avail;
         // test builds: fewer workgroups than CUs (the unit queues must drain with ANY number of resident workgroups, down
         // to one -- the claim the hand-off's deadlock freedom rests on)
         if (g_hook_grid >= 1 && g_hook_grid < wgs) wgs = g_hook_grid;

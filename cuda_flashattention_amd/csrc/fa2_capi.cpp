@@ -328,6 +328,7 @@ static int backward_block_impl(const void* Q, const void* K, const void* V, cons
         f.RC = (float*)((char*)workspace + align256((size_t)B * H * q_hs * sizeof(float)));
         f.q_hs = q_hs; f.k_hs = k_hs; f.q_row0 = 0; f.scale = softmax_scale; f.causal = causal ? 1 : 0; f.causal_shift = 0;
         f.phases = 8 | (phases & 1);
+        f.reserve_cus = (phases & FA2_PHASE_LEAVE_ROOM) ? 16 : 0;
         char* acc = (char*)workspace + bwd_base_ws(B, H, q_len);
         return hip_status(fa2::launch_bwd_fused_bf16(f, (float*)acc, (int*)(acc + align256((size_t)B * H * q_len * head_dim * 4)), 1,
                                                      (hipStream_t)stream));

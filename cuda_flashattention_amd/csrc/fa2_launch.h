@@ -61,6 +61,7 @@ struct BwdArgs {
     int causal;       // key j is visible to local row i iff j <= i + causal_shift
     int causal_shift;
     int phases;       // bit 0: D = rowsum(dO o O), bit 1: dQ kernel, bit 2: dK/dV kernel (7 = all)
+    int reserve_cus;  // single-kernel form: CUs its persistent grid leaves free (for a communication kernel on another stream)
 };
 
 hipError_t launch_bwd_bf16(const BwdArgs& a, hipStream_t stream);

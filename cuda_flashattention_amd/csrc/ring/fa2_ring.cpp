@@ -535,12 +535,15 @@ static int ring_backward_impl(fa2_ring_ctx* c,
 
     // The two main kernels on the block (local rows) x (owner's keys); *rows_q / *rows_k: how many rows of every
     // head of the dQ / dK, dV pieces it defines, and where the dQ rows start.
+    // with more than one rank the exchange of the previous step's pieces runs beside the block kernels: the single-kernel
+    // form then leaves a few CUs to RCCL (fa2_mi355x.h: FA2_PHASE_LEAVE_ROOM)
+    const int both = 6 | (P > 1 ? FA2_PHASE_LEAVE_ROOM : 0);
     auto block = [&](const void* Kc, const void* Vc, int owner, int par, int* q0, int* nq, int* nk) -> int {
         if (!causal || owner == rank) {
             *q0 = 0; *nq = local_seq_len; *nk = local_seq_len;
             return be.backward_block(be.user, Q_local, Kc, Vc, O_local, L_local, dO_local, tq, tk(par), tv(par), B, H, local_seq_len,
                                      local_seq_len, head_dim, softmax_scale, dtype, 0, 0, 0, causal ? 1 : 0, 0, bws, pl.ws_bytes,
-                                     stream, 6);
+                                     stream, both);
         }
         if (owner < rank) {           // the owner's first chunk of keys, every local row
             *q0 = 0; *nq = local_seq_len; *nk = half;

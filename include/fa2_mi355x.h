@@ -165,7 +165,11 @@ int fa2_backward_phases(const void* Q, const void* K, const void* V, const void*
  * fa2_backward does: a DENSE SQUARE block (q_len = kv_len, dense strides, q_row0 = 0, no shift) of head_dim 128 and a
  * length that is a multiple of 256 runs the single five-product kernel -- provided the workspace is
  * fa2_backward_workspace_bytes(B, H, q_len, ...) (room for its running sums) and the device is the validated layout
- * (fa2_backward_plan) -- every other block the dQ and dK/dV kernels.  A single bit (2 or 4) always runs that kernel. */
+ * (fa2_backward_plan) -- every other block the dQ and dK/dV kernels.  A single bit (2 or 4) always runs that kernel.
+ * FA2_PHASE_LEAVE_ROOM (bit 4) asks the single kernel to leave 16 of the device's CUs free: its persistent workgroups fill a
+ * CU's register file for the whole launch, so a kernel on another stream that must run CONCURRENTLY (the ring backward's RCCL
+ * exchange of the previous step's dK / dV pieces) would otherwise wait for the launch to end.  No effect on the results. */
+#define FA2_PHASE_LEAVE_ROOM 16
 int fa2_backward_block(const void* Q, const void* K, const void* V, const void* O, const float* L,
                        const void* dO, void* dQ, void* dK, void* dV,
                        int B, int H, int q_len, int kv_len, int head_dim, float softmax_scale, int dtype,
