@@ -58,8 +58,13 @@ namespace {
 
 int hb_stream_create(void*, void** out)
 {
+    // the ring's private streams carry the exchanges: highest priority, so that an RCCL kernel is dispatched as soon as a CU
+    // frees up beside the step kernels of the caller's stream (they fill the chip)
     hipStream_t s = nullptr;
-    hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    int least = 0, greatest = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, greatest);
+    if (e != hipSuccess) e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
     *out = (void*)s;
     return hip_status(e);
 }
