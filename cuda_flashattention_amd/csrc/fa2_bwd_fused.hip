@@ -146,6 +146,9 @@ struct FusedArgs {
     float* dQacc;       // fp32 [BH][N][128]: zeroed by the launcher and atomically added to (CHAIN = false);
                         // the running sums as [BH][N / 32][wave][g][lane] x 4 floats (CHAIN = true: fused_dq_out_chain_kernel)
     int* ctl;           // control block (CHAIN = true)
+    int npad;           // seq_len rounded up to a multiple of 256 (== seq_len unless the launch is ragged: CHAIN only)
+    const float* rc;    // the row-constant planes the kernel reads: b.RC ([2][BH][seq_len]), or for a ragged launch their padded
+                        // copy [2][BH][npad] whose rows >= seq_len hold (-1e30, 0): P = 0 and dS = 0 there
     int fault;          // FA2_TEST_HOOKS builds only (tests/loopback/libfa2_mi355x_hooks.so): key block 1 of every head never
                         // publishes its progress.  The product build has neither the switch nor the code it guards.
 };
@@ -212,9 +215,12 @@ __device__ __forceinline__ bool fused_spin_over(int* ctl, int spins)
 //     waits only for units taken before it) -- the longest first -- and the masked bodies are a unit's last.  (Round 2 handed
 //     the sums DOWN to key block 0 and had to take the longest units last: the last head of every XCD then ended with one
 //     workgroup walking 256 steps alone.)
-template <bool CHAIN, bool CAUSAL>
+// RAGGED (chained forms): seq_len is not a multiple of 256 -- loops, running-sum layout and row-constant planes are built on
+// the padded length fp.npad; a separate instantiation, so that the kernels of the aligned shapes carry none of it.
+template <bool CHAIN, bool CAUSAL, bool RAGGED = false>
 __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) fa2_bwd_fused_kernel(FusedArgs fp)
 {
+    static_assert(CHAIN || !RAGGED, "the atomics form has no ragged variant");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const BwdArgs& p = fp.b;
     constexpr int D = 128, ROWB = 256, KS = 8, DT = 4;
@@ -231,12 +237,13 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ki = lane & 31;
     const int h = lane >> 5;
-    const int N = p.Nk;                          // square, dense: Nq == Nk == q_hs == k_hs
-    const int ncb = N / 256;
-    const int ntiles = N / TROWS;
+    const int N = p.Nk;                          // square, dense: Nq == Nk == q_hs == k_hs; the TRUE length (tensor ranges, stores)
+    const int NP = RAGGED ? fp.npad : N;         // the length the loops, the running-sum layout and the planes are built on
+    const int ncb = NP / 256;
+    const int ntiles = NP / TROWS;
     const int niter = ((ntiles + 1 + 5) / 6) * 6;        // bodies come in sixes (ring of 3 x dS parity); the extra ones see zero rows
     const float c2 = p.scale * kLog2e;
-    const size_t rc_plane = (size_t)p.BH * N;
+    const size_t rc_plane = (size_t)p.BH * NP;
 
     // ---- loop-invariant LDS addresses
     const uint32_t lbase = (uint32_t)(uintptr_t)smem;
@@ -268,7 +275,7 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
     const int prow = wave * RPI + drow;
     const int doff = drow * ROWB + 16 * ((lds_off<D>(prow, dslot) - ROWB * prow) >> 4);
     const uint32_t dqv = CHAIN ? (uint32_t)(wave * 4096 + lane * 16) : (uint32_t)(((4 * h) * D + 32 * wave + ki) * 4);
-    const auto rc_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.RC, 0, (int)(2 * rc_plane * 4), 0x00020000);
+    const auto rc_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)fp.rc, 0, (int)(2 * rc_plane * 4), 0x00020000);
 
     int xcc = 0;
     if constexpr (CHAIN) {
@@ -327,8 +334,12 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
         // passes through compiler-allocated registers
         {
             const int lane_u = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));    // recomputed: nothing per-lane
-            const char* v0 = Vh + (size_t)(kw0 + (lane_u & 31)) * ROWB + 16 * (lane_u >> 5);             // is kept (spilled) across units
-            const char* v1 = v0 + 32 * ROWB;
+            // (keys past the end of a ragged sequence: any finite row will do -- their P is masked to zero -- so the address
+            // is clamped; everything else reaches them through range-checked buffer resources)
+            const int vk0 = RAGGED ? min(kw0 + (lane_u & 31), N - 1) : kw0 + (lane_u & 31);
+            const int vk1 = RAGGED ? min(kw0 + 32 + (lane_u & 31), N - 1) : kw0 + 32 + (lane_u & 31);
+            const char* v0 = Vh + (size_t)vk0 * ROWB + 16 * (lane_u >> 5);             // is kept (spilled) across units
+            const char* v1 = Vh + (size_t)vk1 * ROWB + 16 * (lane_u >> 5);
             static_for<KS>([&](auto S) { fused_load_vfrag<VF, KS, decltype(S)::value>(v0, v1); });
             const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, N * ROWB, 0x00020000);
 #pragma unroll
@@ -344,7 +355,7 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
         // ---- LDS-DMA staging of a 32-row Q / dO tile + its row constants into ring slot `buf`
         const auto q_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Qh, 0, N * ROWB, 0x00020000);
         const auto g_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Gh, 0, N * ROWB, 0x00020000);
-        const int rcoff = (int)(((wave == 0 ? 0 : rc_plane) + (size_t)head * N + (lane & 31)) * 4);
+        const int rcoff = (int)(((wave == 0 ? 0 : rc_plane) + (size_t)head * NP + (lane & 31)) * 4);
         auto stage = [&](int t, int buf) {
             char* b = smem + QRING + buf * BUFB;
 #pragma unroll
@@ -360,7 +371,11 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
         // steps u = 0 .. n_u - 1 of this unit work on sub-tile tl(u); the bodies from `first_masked` on carry the causal mask
         const int n_u = CAUSAL ? ntiles - 8 * cb : ntiles;
         const int niter_u = CAUSAL ? ((n_u + 1 + 5) / 6) * 6 : niter;
-        const int first_masked = CAUSAL ? ((n_u - 8) / 6) * 6 : niter_u;
+        // non-causal, ragged: the LAST key block holds keys past the end (their K rows read as zeros, so S' = -L/scale and P
+        // would not vanish): all of its bodies are the masked ones, the mask being "this lane's key exists".  (Causal: those
+        // keys lie above every existing row's diagonal and the last key block's bodies are all masked anyway.)
+        const bool ragged_unit = RAGGED && !CAUSAL && cb == ncb - 1;
+        const int first_masked = CAUSAL ? ((n_u - 8) / 6) * 6 : (ragged_unit ? 0 : niter_u);
         auto tl = [&](int u) { return CAUSAL ? ntiles - 1 - u : u; };
         stage(tl(0), 0);
         fused_dq_zero<DQT>();
@@ -368,7 +383,7 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
         __syncthreads();                                 // V fragments, K image and the first tile have landed
         asm volatile(FA2_FUSED_PRO : : FA2_FUSED_OPS, [vm] "i"(VMW) : FA2_FUSED_CLOBBERS);
 
-        const auto dq_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(fp.dQacc + (size_t)head * N * D), 0, N * D * 4, 0x00020000);
+        const auto dq_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(fp.dQacc + (size_t)head * NP * D), 0, NP * D * 4, 0x00020000);
         int* const mine = prog_base + head * ncb + cb;
         const int* const prev = mine - 1;                             // the key block this one takes the running sums from
         const int prev_off = (int)((prev - fp.ctl) * 4);
@@ -431,8 +446,13 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
                 int lo0 = 0, lo1 = 0;
                 if constexpr (masked) {      // key - 32 tile - 4 h for the lane's two keys (recomputed: nothing per-lane is kept)
                     const int lane_m = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-                    lo0 = kw0 + (lane_m & 31) - 4 * (lane_m >> 5) - TROWS * tl(t);
-                    lo1 = lo0 + 32;
+                    if constexpr (CAUSAL) {
+                        lo0 = kw0 + (lane_m & 31) - 4 * (lane_m >> 5) - TROWS * tl(t);
+                        lo1 = lo0 + 32;
+                    } else {                 // keep (lo <= row) everything of an existing key, nothing of a key past the end
+                        lo0 = kw0 + (lane_m & 31) < N ? -0x40000000 : 0x40000000;
+                        lo1 = kw0 + 32 + (lane_m & 31) < N ? -0x40000000 : 0x40000000;
+                    }
                 }
 #ifdef FA2_FUSED_STATS2
                 const uint64_t b0 = __builtin_readcyclecounter();
@@ -463,7 +483,7 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
         // sixes whose every step is FAST: t >= 6 (so t >= 1), t + 5 + 1 < n_u; the causal form's masked bodies come behind them
         const int fast_end = CHAIN ? n_u - 2 : -1;                            // last step that may be FAST
         {
-            const int plain_end = CAUSAL ? first_masked : niter_u;
+            const int plain_end = first_masked;
             int t = 0;
             asm volatile("" : "+s"(t));          // not a literal: the bodies take values derived from it in SGPR operands
             if (t < plain_end) { six(std::false_type{}, std::false_type{}, t); t += 6; }
@@ -471,7 +491,7 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
             for (; t + 5 <= fast_end && t < plain_end; t += 6) six(std::false_type{}, std::true_type{}, t);
 #pragma unroll 1
             for (; t < plain_end; t += 6) six(std::false_type{}, std::false_type{}, t);
-            if constexpr (CAUSAL) {
+            if constexpr (CHAIN && (CAUSAL || RAGGED)) {
 #pragma unroll 1
                 for (; t < niter_u; t += 6) six(std::true_type{}, std::false_type{}, t);
             }
@@ -506,7 +526,7 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
                     const auto s0 = __builtin_amdgcn_permlane32_swap(x[0], y[0], false, false);
                     const auto s1 = __builtin_amdgcn_permlane32_swap(x[1], y[1], false, false);
                     const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
-                    *reinterpret_cast<u32x4*>(dst + 2 * (32 * dt + 16 * gp)) = o;
+                    if (!RAGGED || key < N) *reinterpret_cast<u32x4*>(dst + 2 * (32 * dt + 16 * gp)) = o;      // (ragged: keys past the end)
                 };
                 emit(pack4(acc_read<RK>(), acc_read<RK + 1>(), acc_read<RK + 2>(), acc_read<RK + 3>(), p.scale),
                      pack4(acc_read<RK + 4>(), acc_read<RK + 5>(), acc_read<RK + 6>(), acc_read<RK + 7>(), p.scale), dKk);
@@ -545,21 +565,35 @@ __global__ void __launch_bounds__(256) fa2_bwd_fused_dq_out_kernel(const float* 
     }
 }
 
-// the same for the chained kernel's layout: slot i = (((head * N / 32 + tile) * 4 + wave) * 4 + g) * 64 + lane holds rows
-// 32 tile + 8 g + 4 (lane >> 5) + (0 .. 3) of column 32 wave + (lane & 31)
+// the same for the chained kernel's layout: slot i = (((head * NP / 32 + tile) * 4 + wave) * 4 + g) * 64 + lane holds rows
+// 32 tile + 8 g + 4 (lane >> 5) + (0 .. 3) of column 32 wave + (lane & 31); NP = N rounded up to 256, rows >= N are not stored
 __global__ void __launch_bounds__(256) fa2_bwd_fused_dq_out_chain_kernel(const float* __restrict__ acc, __bf16* __restrict__ dQ, size_t n4, float scale,
-                                                                          const int* __restrict__ err)
+                                                                          const int* __restrict__ err, int N, int NP)
 {
     const float poison = *err ? __builtin_nanf("") : 0.0f;
     const size_t stride = (size_t)gridDim.x * 256;
+    const size_t tiles = (size_t)(NP / 32);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
         const f32x4 a = reinterpret_cast<const f32x4*>(acc)[i];
         const int lane = (int)(i & 63), g = (int)((i >> 6) & 3), wave = (int)((i >> 8) & 3);
-        const size_t row = (i >> 10) * 32 + 8 * g + 4 * (lane >> 5);
-        __bf16* o = dQ + row * 128 + 32 * wave + (lane & 31);
+        const size_t tg = i >> 10, head = tg / tiles;
+        const int row = (int)(tg % tiles) * 32 + 8 * g + 4 * (lane >> 5);
+        __bf16* o = dQ + (head * (size_t)N + row) * 128 + 32 * wave + (lane & 31);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[(size_t)e * 128] = (__bf16)(a[e] * scale + poison);
+        for (int e = 0; e < 4; ++e)
+            if (row + e < N) o[(size_t)e * 128] = (__bf16)(a[e] * scale + poison);
     }
+}
+
+// ragged launches: the row-constant planes [2][BH][N] copied to [2][BH][NP] with (-1e30, 0) in the rows past the end -- a row
+// that does not exist then has S' = -1e30, P = exp2(-huge) = 0 and dS = 0 whatever the (zero) Q / dO rows give
+__global__ void __launch_bounds__(256) fa2_bwd_fused_rcpad_kernel(const float* __restrict__ rc, float* __restrict__ out, int BH, int N, int NP)
+{
+    const size_t per = (size_t)BH * NP, i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * per) return;
+    const size_t plane = i / per, r = i % per, head = r / NP;
+    const int row = (int)(r % NP);
+    out[i] = row < N ? rc[plane * (size_t)BH * N + head * (size_t)N + row] : (plane == 0 ? -1.0e30f : 0.0f);
 }
 
 // The ordered hand-off relies on one hardware property: a workgroup's plain stores land in the L2 of the XCC whose id it
@@ -592,12 +626,14 @@ hipError_t bwd_fused_read_error(const int* ctl, int* err, hipStream_t stream)
 }
 
 // (the last 8 ints per unit are only written by -DFA2_FUSED_STATS builds: tools/gpu_stats_fused.py)
-size_t bwd_fused_ctl_bytes(int BH, int N) { return (size_t)(kCtlHeadmap + 16 * (BH + 1) + 9 * BH * (N / 256)) * sizeof(int); }
+size_t bwd_fused_ctl_bytes(int BH, int N) { return (size_t)(kCtlHeadmap + 16 * (BH + 1) + 9 * BH * ((N + 255) / 256)) * sizeof(int); }
 
-hipError_t launch_bwd_fused_bf16(const BwdArgs& a, float* dQacc, int* ctl, int mode, hipStream_t stream)
+hipError_t launch_bwd_fused_bf16(const BwdArgs& a, float* dQacc, int* ctl, int mode, hipStream_t stream, float* rcpad)
 {
-    if (a.d != 128 || a.Nq != a.Nk || a.Nk % 256 != 0 || a.q_hs != a.Nq || a.k_hs != a.Nk || a.q_row0 != 0)
-        return hipErrorInvalidValue;
+    const int npad = (a.Nk + 255) / 256 * 256;
+    const bool ragged = npad != a.Nk;            // chained form only: needs `rcpad` (2 BH npad floats)
+    if (a.d != 128 || a.Nq != a.Nk || a.Nk < 1 || a.q_hs != a.Nq || a.k_hs != a.Nk || a.q_row0 != 0) return hipErrorInvalidValue;
+    if (ragged && (mode != 1 || !rcpad)) return hipErrorInvalidValue;
     if (a.causal && (mode != 1 || a.causal_shift != 0)) return hipErrorInvalidValue;
     if (mode == 1 && (a.phases & 8) && !bwd_fused_device_ok(nullptr)) return hipErrorNotSupported;
     hipError_t e = hipSuccess;
@@ -608,9 +644,16 @@ hipError_t launch_bwd_fused_bf16(const BwdArgs& a, float* dQacc, int* ctl, int m
         if (e != hipSuccess) return e;
     }
     if (!(a.phases & 8)) return hipSuccess;
-    const size_t elems = (size_t)a.BH * a.Nq * 128;
-    const int units = a.BH * (a.Nk / 256);
-    FusedArgs fa{a, dQacc, ctl, g_hook_fault};
+    const size_t elems = (size_t)a.BH * npad * 128;
+    const int units = a.BH * (npad / 256);
+    if (ragged) {
+        const size_t n = (size_t)2 * a.BH * npad;
+        hipLaunchKernelGGL(fa2_bwd_fused_rcpad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const float*)a.RC, rcpad,
+                           a.BH, a.Nk, npad);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    FusedArgs fa{a, dQacc, ctl, npad, ragged ? (const float*)rcpad : (const float*)a.RC, g_hook_fault};
     constexpr int lds = FA2_FUSED_LDS + 16;
     if (mode == 0) {
         e = hipMemsetAsync(dQacc, 0, elems * 4, stream);
@@ -642,10 +685,19 @@ hipError_t launch_bwd_fused_bf16(const BwdArgs& a, float* dQacc, int* ctl, int m
         if (g_hook_grid >= 1 && g_hook_grid < wgs) wgs = g_hook_grid;
         FA2_HOOK_NOTE_GRID(wgs);
         const dim3 grid((unsigned)wgs);
-        if (a.causal) {
+        static bool set_cr[64] = {}, set_tr[64] = {};
+        if (a.causal && ragged) {
+            e = ensure_dynamic_lds(fa2_bwd_fused_kernel<true, true, true>, lds, set_cr);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((fa2_bwd_fused_kernel<true, true, true>), grid, dim3(256), lds, stream, fa);
+        } else if (a.causal) {
             e = ensure_dynamic_lds(fa2_bwd_fused_kernel<true, true>, lds, set_c);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL((fa2_bwd_fused_kernel<true, true>), grid, dim3(256), lds, stream, fa);
+        } else if (ragged) {
+            e = ensure_dynamic_lds(fa2_bwd_fused_kernel<true, false, true>, lds, set_tr);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((fa2_bwd_fused_kernel<true, false, true>), grid, dim3(256), lds, stream, fa);
         } else {
             e = ensure_dynamic_lds(fa2_bwd_fused_kernel<true, false>, lds, set_t);
             if (e != hipSuccess) return e;
@@ -659,7 +711,7 @@ hipError_t launch_bwd_fused_bf16(const BwdArgs& a, float* dQacc, int* ctl, int m
                            (const int*)nullptr);
     else
         hipLaunchKernelGGL(fa2_bwd_fused_dq_out_chain_kernel, dim3(4096), dim3(256), 0, stream, dQacc, (__bf16*)a.dQ, elems / 4, a.scale,
-                           ctl + kCtlError);
+                           ctl + kCtlError, a.Nk, npad);
     return hipGetLastError();
 }
 

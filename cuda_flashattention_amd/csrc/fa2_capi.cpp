@@ -173,15 +173,28 @@ int fa2_forward_fp8(const void* Q, const void* K, const void* V, void* O, float*
 // D = rowsum(dO o O), then the two row-constant planes (-L/scale, -D) of the kernels that own key blocks
 static size_t bwd_base_ws(int B, int H, int rows) { return 3 * align256((size_t)B * H * rows * sizeof(float)); }
 
-// shapes the single-kernel (five-product) backward takes: csrc/fa2_bwd_fused.hip
+// shapes the single-kernel (five-product) backward takes: csrc/fa2_bwd_fused.hip.  Any seq_len: its loops run on the length
+// rounded up to a multiple of 256 (keys past the end are masked, rows past the end get row constants that make P vanish), so
+// it is taken whenever that padding costs less than the two extra block products of the two-kernel form, whose own tiles are
+// 64 keys: 5 x roundup(N, 256) <= 7 x roundup(N, 64) -- every N >= 897, and the N just below a multiple of 256 under that.
+static int fused_npad(int n) { return (n + 255) / 256 * 256; }
 static bool bwd_fused_shape(int seq_len, int head_dim, int dtype)
 {
-    return dtype == FA2_DTYPE_BF16 && head_dim == 128 && seq_len % 256 == 0 && (long long)seq_len * head_dim * 4 <= 0x7fffffffLL;
+    if (dtype != FA2_DTYPE_BF16 || head_dim != 128 || seq_len < 1) return false;
+    const long long np = fused_npad(seq_len), n64 = (seq_len + 63) / 64 * 64;
+    return 5 * np <= 7 * n64 && np * head_dim * 4 <= 0x7fffffffLL;
 }
-static size_t bwd_fused_ws(int B, int H, int seq_len, int head_dim)
+// workspace behind the D / row-constant planes: fp32 dQ sums [BH][NP][d] | control block | (ragged only) padded row constants
+struct FusedWs { float* acc; int* ctl; float* rcpad; size_t bytes; };
+static FusedWs fused_ws(void* base, int B, int H, int seq_len, int head_dim)
 {
-    return align256((size_t)B * H * seq_len * head_dim * 4) + align256(fa2::bwd_fused_ctl_bytes(B * H, seq_len));
+    const int np = fused_npad(seq_len);
+    const size_t a = align256((size_t)B * H * np * head_dim * 4), c = align256(fa2::bwd_fused_ctl_bytes(B * H, np));
+    const size_t r = np != seq_len ? align256((size_t)2 * B * H * np * sizeof(float)) : 0;
+    char* b = (char*)base;
+    return FusedWs{(float*)b, (int*)(b + a), r ? (float*)(b + a + c) : nullptr, a + c + r};
 }
+static size_t bwd_fused_ws(int B, int H, int seq_len, int head_dim) { return fused_ws(nullptr, B, H, seq_len, head_dim).bytes; }
 
 // FA2_BACKWARD_PATH=two_kernel keeps fa2_backward on the two deterministic kernels for every shape (A/B runs, triage)
 static bool bwd_fused_allowed()
@@ -245,9 +258,8 @@ int fa2_backward_phases(const void* Q, const void* K, const void* V, const void*
             a.RC = (float*)((char*)workspace + align256((size_t)B * H * seq_len * sizeof(float)));
             a.q_hs = seq_len; a.k_hs = seq_len; a.q_row0 = 0; a.scale = softmax_scale; a.causal = causal ? 1 : 0; a.causal_shift = 0;
             a.phases = phases == 7 ? 9 : (phases & 9);
-            char* acc = (char*)workspace + bwd_base_ws(B, H, seq_len);
-            return hip_status(fa2::launch_bwd_fused_bf16(a, (float*)acc, (int*)(acc + align256((size_t)B * H * seq_len * head_dim * 4)), 1,
-                                                         (hipStream_t)stream));
+            const FusedWs w = fused_ws((char*)workspace + bwd_base_ws(B, H, seq_len), B, H, seq_len, head_dim);
+            return hip_status(fa2::launch_bwd_fused_bf16(a, w.acc, w.ctl, 1, (hipStream_t)stream, w.rcpad));
         }
         return backward_block_impl(Q, K, V, O, L, dO, dQ, dK, dV, B, H, seq_len, seq_len, head_dim, softmax_scale, dtype, 0, 0, 0,
                                    causal, 0, workspace, workspace_bytes, stream, phases, false);     // phases 6 here = the two kernels
@@ -263,7 +275,8 @@ int fa2_backward_phases(const void* Q, const void* K, const void* V, const void*
 int fa2_backward_plan(int B, int H, int seq_len, int head_dim, int dtype, int causal, const char** reason)
 {
     (void)causal;
-    static const char* const kShape = "two kernels: the single kernel takes bf16, head_dim 128, seq_len a multiple of 256";
+    static const char* const kShape = "two kernels: the single kernel takes bf16, head_dim 128, and a seq_len whose padding to a "
+                                      "multiple of 256 costs less than two block products (5 roundup(N,256) <= 7 roundup(N,64))";
     static const char* const kEnv = "two kernels: FA2_BACKWARD_PATH=two_kernel";
     static const char* const kF32 = "fp32 path (exact f32 MFMA kernels)";
     if (reason) *reason = "";
@@ -289,9 +302,9 @@ int fa2_backward_status(const void* workspace, size_t workspace_bytes, int B, in
         return hip_status(hipStreamSynchronize((hipStream_t)stream));
     }
     if (workspace_bytes < fa2_backward_workspace_bytes(B, H, seq_len, head_dim, dtype)) return FA2_ERR_WORKSPACE;
-    const char* acc = (const char*)workspace + bwd_base_ws(B, H, seq_len);
+    const FusedWs w = fused_ws((char*)const_cast<void*>(workspace) + bwd_base_ws(B, H, seq_len), B, H, seq_len, head_dim);
     int err = 0;
-    hipError_t e = fa2::bwd_fused_read_error((const int*)(acc + align256((size_t)B * H * seq_len * head_dim * 4)), &err, (hipStream_t)stream);
+    hipError_t e = fa2::bwd_fused_read_error(w.ctl, &err, (hipStream_t)stream);
     if (e != hipSuccess) return hip_status(e);
     return err ? FA2_ERR_HANDOFF_TIMEOUT : FA2_OK;
 }
@@ -329,9 +342,8 @@ static int backward_block_impl(const void* Q, const void* K, const void* V, cons
         f.q_hs = q_hs; f.k_hs = k_hs; f.q_row0 = 0; f.scale = softmax_scale; f.causal = causal ? 1 : 0; f.causal_shift = 0;
         f.phases = 8 | (phases & 1);
         f.reserve_cus = (phases & FA2_PHASE_LEAVE_ROOM) ? 16 : 0;
-        char* acc = (char*)workspace + bwd_base_ws(B, H, q_len);
-        return hip_status(fa2::launch_bwd_fused_bf16(f, (float*)acc, (int*)(acc + align256((size_t)B * H * q_len * head_dim * 4)), 1,
-                                                     (hipStream_t)stream));
+        const FusedWs w = fused_ws((char*)workspace + bwd_base_ws(B, H, q_len), B, H, q_len, head_dim);
+        return hip_status(fa2::launch_bwd_fused_bf16(f, w.acc, w.ctl, 1, (hipStream_t)stream, w.rcpad));
     }
     fa2::BwdArgs a{};
     a.Q = Q; a.K = K; a.V = V; a.O = O; a.dO = dO; a.L = L; a.dQ = dQ; a.dK = dK; a.dV = dV;
@@ -369,6 +381,7 @@ int fa2_backward_fused(const void* Q, const void* K, const void* V, const void* 
     if (!st) st = check_bwd_planes(B, H, seq_len);
     if (st) return st;
     if (!bwd_fused_shape(seq_len, head_dim, FA2_DTYPE_BF16) || (mode != 0 && mode != 1)) return FA2_ERR_UNSUPPORTED;
+    if (mode == 0 && seq_len % 256 != 0) return FA2_ERR_UNSUPPORTED;          // the atomics form has no ragged variant
     if (mode == 1 && !fa2::bwd_fused_device_ok(nullptr)) return FA2_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < fa2_backward_fused_workspace_bytes(B, H, seq_len, head_dim)) return FA2_ERR_WORKSPACE;
     fa2::BwdArgs a{};
@@ -376,9 +389,8 @@ int fa2_backward_fused(const void* Q, const void* K, const void* V, const void* 
     a.D = (float*)workspace; a.BH = B * H; a.Nq = seq_len; a.Nk = seq_len; a.d = head_dim;
     a.RC = (float*)((char*)workspace + align256((size_t)B * H * seq_len * sizeof(float)));
     a.q_hs = seq_len; a.k_hs = seq_len; a.q_row0 = 0; a.scale = softmax_scale; a.causal = 0; a.causal_shift = 0; a.phases = 9;
-    char* acc = (char*)workspace + bwd_base_ws(B, H, seq_len);
-    return hip_status(fa2::launch_bwd_fused_bf16(a, (float*)acc, (int*)(acc + align256((size_t)B * H * seq_len * head_dim * 4)), mode,
-                                                 (hipStream_t)stream));
+    const FusedWs w = fused_ws((char*)workspace + bwd_base_ws(B, H, seq_len), B, H, seq_len, head_dim);
+    return hip_status(fa2::launch_bwd_fused_bf16(a, w.acc, w.ctl, mode, (hipStream_t)stream, w.rcpad));
 }
 
 int fa2_forward_step(const void* Q, const void* K, const void* V,

@@ -65,11 +65,12 @@ struct BwdArgs {
 };
 
 hipError_t launch_bwd_bf16(const BwdArgs& a, hipStream_t stream);
-// Single-kernel five-product backward (fa2_bwd_fused.hip): d = 128, dense, square, seq_len % 256 == 0; causal with mode 1 only.
-// dQacc: [BH][N][128] fp32 scratch; ctl: bwd_fused_ctl_bytes of scratch; mode 0 = dQ by fp32 atomics, 1 = dQ handed from key
-// block to key block in a fixed order (deterministic).  hipErrorInvalidValue for shapes it does not take.
+// Single-kernel five-product backward (fa2_bwd_fused.hip): d = 128, dense, square; causal with mode 1 only.
+// dQacc: [BH][NP][128] fp32 scratch (NP = N rounded up to 256); ctl: bwd_fused_ctl_bytes of scratch; mode 0 = dQ by fp32
+// atomics (N % 256 == 0 only), 1 = dQ handed from key block to key block in a fixed order (deterministic; any N: a ragged
+// launch also needs rcpad, 2 BH NP floats, for the padded row-constant planes).  hipErrorInvalidValue for shapes it does not take.
 size_t bwd_fused_ctl_bytes(int BH, int N);
-hipError_t launch_bwd_fused_bf16(const BwdArgs& a, float* dQacc, int* ctl, int mode, hipStream_t stream);
+hipError_t launch_bwd_fused_bf16(const BwdArgs& a, float* dQacc, int* ctl, int mode, hipStream_t stream, float* rcpad = nullptr);
 // Whether the current device has the layout the ordered hand-off (mode 1) was validated on; *why = a static sentence.
 bool bwd_fused_device_ok(const char** why);
 // Synchronises `stream` and reads the error word a chained launch leaves in its control block (non-zero: a bounded wait

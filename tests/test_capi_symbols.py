@@ -65,7 +65,10 @@ def test_argument_checking_status_codes():
     fused = lib.fa2_backward_workspace_bytes(4, 16, 8192, 128, 0)                # + fp32 dQ sums + a control block
     assert base + 4 * 16 * 8192 * 128 * 4 < fused < base + 4 * 16 * 8192 * 128 * 4 + (1 << 20)
     assert lib.fa2_backward_fused_workspace_bytes(4, 16, 8192, 128) == fused
-    assert lib.fa2_backward_workspace_bytes(4, 16, 8000, 128, 0) == 3 * ((4 * 16 * 8000 * 4 + 255) // 256 * 256)   # N % 256 != 0
+    # ragged seq_len: the single kernel pads to a multiple of 256 and is taken when 5 roundup(N, 256) <= 7 roundup(N, 64)
+    assert lib.fa2_backward_workspace_bytes(4, 16, 300, 128, 0) == 3 * ((4 * 16 * 300 * 4 + 255) // 256 * 256)     # 2560 > 2240: two kernels
+    ragged = lib.fa2_backward_workspace_bytes(4, 16, 8000, 128, 0)                                                 # 40960 <= 56000: single
+    assert ragged > 3 * ((4 * 16 * 8000 * 4 + 255) // 256 * 256) + 4 * 16 * 8192 * 128 * 4 + 2 * 4 * 16 * 8192 * 4
     assert b"head_dim" in lib.fa2_status_string(-3)
 
 

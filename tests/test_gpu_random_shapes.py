@@ -45,15 +45,20 @@ def test_bf16_forward_backward_random_shapes():
 
 def test_bf16_backward_random_shapes_of_the_single_kernel():
     """The same sweep over the shapes fa2_backward gives to its single five-product kernel: d = 128, seq_len a multiple of
-    256 (1 .. 12 key blocks per head), any batch and head count, causal on and off, value scales that move the softmax."""
+    256 (1 .. 12 key blocks per head) or -- every other case -- a ragged length the padding rule admits (897 .. 3072, checked
+    with fa2_backward_plan), any batch and head count, causal on and off, value scales that move the softmax."""
+    import ctypes
     import cuda_flashattention_amd as fa
     import oracle
     f = lambda t: t.float().cpu().numpy()
     rng = np.random.default_rng(909)
     for i in range(14):
         B, H, N = int(rng.integers(1, 3)), int(rng.integers(1, 12)), 256 * int(rng.integers(1, 13))
+        if i % 2:
+            N = int(rng.integers(897, 3073))
         causal, amp = bool(rng.integers(0, 2)), float(rng.choice([0.5, 1.0, 3.0]))
         d = 128
+        assert fa._capi.lib().fa2_backward_plan(B, H, N, d, 0, int(causal), ctypes.POINTER(ctypes.c_char_p)()) == 1, N
         g = torch.Generator().manual_seed(500 + i)
         mk = lambda s: ((torch.rand(B, H, N, d, generator=g) - 0.5) * s).bfloat16()
         Q, K, V, dO = mk(amp), mk(amp), mk(1.0), mk(0.4)

@@ -171,22 +171,23 @@ def test_fused_backward_kernel(asm):
     chained form's bodies carry their four dQ stores in front of the barrier and the four running-sum loads behind it, and
     nothing touches scratch."""
     ks = {n: k for n, k in _kernels(asm["fa2_bwd_fused"]).items() if "fa2_bwd_fused_kernelILb" in n}
-    assert len(ks) == 3          # <atomics>, <chain>, <chain, causal>
+    assert len(ks) == 5          # <atomics>, <chain>, <chain, causal>, and the two ragged instantiations of the chained forms
     pat = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
     for name, k in ks.items():
-        chain, causal = "ILb1ELb" in name, "ILb1ELb1E" in name
+        chain, causal, ragged = "ILb1ELb" in name, "ILb1ELb1ELb" in name, name.split("fa2_bwd_fused_kernelILb")[1][8:9] == "1"
         outside, blocks = _split_asm(k["body"])
         for s in outside:
             for m in pat.finditer(s):
                 hi = int(m.group(1)) if m.group(1) else int(m.group(3))
                 assert hi < 39, (name, s)
         assert k["meta"]["total"] == 512 and k["meta"]["agpr"] == 256, (name, k["meta"])
-        nb = 24 if causal else 18      # six-body loops inside the unit loop: first, steady state, last (+ masked); + the 16 zeroing MFMAs
+        nb = 24 if (causal or ragged) else 18      # six-body loops inside the unit loop: first, steady state, last, and masked -- the
+        #                                causal diagonal, or the last key block of a ragged sequence; + the 16 accumulator-zeroing MFMAs
         assert sum("v_mfma_f32_32x32x16_bf16" in l for l in k["body"]) == nb * 80 + 16, name
         assert not any("scratch_" in l for l in k["body"]), name
         bodies = [b for b in _split_asm(k["body"])[1] if sum("v_mfma" in s for s in b) == 80]
         assert len(bodies) == nb
-        assert sum(any(s.startswith("v_cmp_le_i32 vcc") for s in b) for b in bodies) == (6 if causal else 0)
+        assert sum(any(s.startswith("v_cmp_le_i32 vcc") for s in b) for b in bodies) == (6 if (causal or ragged) else 0)
         for b in bodies:
             st = [i for i, s in enumerate(b) if s.startswith("buffer_store_dwordx4")]
             ld = [i for i, s in enumerate(b) if s.startswith("buffer_load_dwordx4 v[")]          # running sums (not the LDS-DMA)
