@@ -144,14 +144,12 @@ def build(D, QBS, par, masked, dma):
                         # P of block j - 2: the same parity as this block's
                         mfma[g + qb] = (f"v_mfma_f32_32x32x16_bf16 {R.o(qb, dt)}, {R.slot(sv)}, {R.pf(par, qb, sp)}, {R.o(qb, dt)}", [ka, kb_])
 
+    # Two passes (the schedule is cyclic): the first learns which gap last consumes each slot, the second places the reads with
+    # "free after the previous body's last consumer".  The rotation restarts with every body -- all bodies take their slots in
+    # the same order, so the early reads a body issues for the next one are the same whatever variant follows.
     allocate(False)
-    # the slot rotation need not close over one body: bodies of the two parities alternate and each is generated on its own,
-    # so the rotation is restarted per body; what matters is that a slot is free when it is taken again (free_after, cyclic)
-    used = ctr[0]
     for i in range(NSLOT):
         busy[i] -= NS
-    # rotate so that the first slot taken in the next body is the one after the last taken here
-    assert used % NSLOT == 0 or True
     ctr[0] = 0
     allocate(True)
 
