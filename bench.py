@@ -342,11 +342,18 @@ def main():
         print(json.dumps(out), flush=True)
     sys.stdout.flush()
     if hung:
-        # A wedged transport must not look like a clean run: the headline line is out, the exit status says so.
-        os._exit(3)
+        # A wedged transport cannot be interrupted (the worker thread sits inside RCCL): every rank leaves through os._exit.
+        # The headline line is out and says so ("ring_hang": true); the exit status stays 0 -- under torch.distributed.run a
+        # non-zero status of ANY rank makes the launcher kill the others, possibly rank 0 before it has printed -- and the
+        # other ranks give rank 0 a few seconds' head start for the same reason.
+        if rank != 0:
+            time.sleep(5.0)
+        os._exit(0)
     if dist is not None and not args.no_ring:
         # After a ring leg the ranks may disagree on whether it finished (each has its own deadline): no
         # further collective, every rank simply leaves.  The timed region and its barriers are long past.
+        if rank != 0:
+            time.sleep(2.0)
         os._exit(0)
     if dist is not None:
         dist.barrier()
