@@ -1,24 +1,29 @@
 // fa2_fwd_fp8.hip -- FlashAttention-2 forward with fp8 (OCP e4m3) Q/K/V for gfx950 (MI355X):
-// BASELINE configs[4] ("FA2 fwd causal long-context, fp8 Q/K/V, N=32768 d=128").  Same algorithm
-// and the same machine mapping as fa2_fwd_bf16.hip (8 waves x 32 query rows, two waves per SIMD,
-// kernel-owned AGPRs, stages as long asm statements, lazy softmax reference, LDS-DMA ring of three
-// 64-key tiles); what differs is the matrix instruction and everything that follows from it:
+// BASELINE configs[4] ("FA2 fwd causal long-context, fp8 Q/K/V, N=32768 d=128").  Same algorithm as the bf16 forward
+// (fa2_fwd1_bf16.hip: S^T = K Q^T so that a row's max and sum are in-lane reductions, P stays in registers, lazy softmax
+// reference, exp2 domain, natural-log L) and, since round 3, the same construction: the main loop is ONE generated asm body
+// per 64 keys (tools/gen_fwd_fp8_body.py -> fa2_fwd_fp8_body.inc), a pipeline two bodies deep --
+//   A  S^T(j) = K(j) Q^T  (4 MFMAs)      P  O^T += V^T(j-2) P^T(j-2)  (4 MFMAs)      VALU: softmax of the keys j-1, maxima of the keys j
+// -- with every LDS read issued ahead of its use behind a counted lgkmcnt, the next tile's LDS-DMA issued from inside the
+// bodies and the softmax state in registers the bodies name (hipcc owns v0..v31 only).  Workgroup = 8 waves x 32 query rows,
+// two waves per SIMD: the kernel is bound by VALU issue (4 VALU instructions per S element against a quarter of the MFMA
+// cycles of bf16 d = 128), and two waves issue VALU instructions at ~4 clocks each against ~7 for a wave alone.
 //
-//   * v_mfma_f32_32x32x64_f8f6f4 contracts 64 values per instruction (32 bytes per lane and
-//     operand): S^T = K Q^T over d = 128 is two MFMAs per 32x32 tile, O^T += V^T P^T over a 64-key
-//     tile is ONE per 32-column tile of O.
-//   * Both operands of an MFMA pair lane-half h, slot j with lane-half h, slot j; which k index the
-//     hardware calls that does not matter as long as both operands are gathered the same way.  For
-//     S^T both K and Q fragments take bytes 64 s + 32 h .. + 31 of their row.  For P V the B operand
-//     is the exponentiated S^T accumulator, whose register r in lane-half h is accumulator row
-//     (r & 3) + 8 (r >> 2) + 4 h; the K rows are therefore fed in a permuted order (pi below) that
-//     makes those 16 registers the CONSECUTIVE keys 16 h .. 16 h + 15 of the 32-key block.  Packed
-//     four to a register they are k-slots 0..15 (first key block) and 16..31 (second) of the B
-//     operand, and the matching A operand is two plain 16-byte row reads of a V^T tile -- which is why
-//     V is transposed once per call into a workspace ([d][N] per head, fa2_fp8_transpose_kernel)
-//     instead of being read through transposed LDS loads.
-//   * P is rounded to e4m3 (v_cvt_pk_fp8_f32) for the second product; with the lazy reference P never
-//     exceeds e^6 = 403 < 448, the largest e4m3 value.  The row sum is taken from the unrounded fp32 p.
+// What follows from the matrix instruction:
+//   * v_mfma_f32_32x32x64_f8f6f4 contracts 64 values per instruction (32 bytes per lane and operand): S^T = K Q^T over
+//     d = 128 is two MFMAs per 32x32 tile, O^T += V^T P^T over 64 keys is ONE per 32-column tile of O.
+//   * Both operands of an MFMA pair lane-half h, slot j with lane-half h, slot j; which k index the hardware calls that
+//     does not matter as long as both operands are gathered the same way.  For S^T both K and Q fragments take bytes
+//     64 s + 32 h .. + 31 of their row.  For P V the B operand is the exponentiated S^T accumulator, whose register r in
+//     lane-half h is accumulator row (r & 3) + 8 (r >> 2) + 4 h; the K rows are therefore fed in a permuted order (pi
+//     below) that makes those 16 registers the CONSECUTIVE keys 16 h .. 16 h + 15 of the 32-key block.  Packed four to a
+//     register they are k-slots 0..15 (first key block) and 16..31 (second) of the B operand, and the matching A operand
+//     is two plain 16-byte row reads of a V^T tile -- which is why V is transposed once per call into a workspace
+//     ([d][Npad] per head, fa2_fp8_transpose_kernel: 40 us of 2.2 ms at the BASELINE shape).  Reading V through
+//     ds_read_b64_tr_b8 instead would take four LDS instructions per fragment where the V^T image takes two: eight more
+//     issue slots per 64 keys and wave in a kernel whose bound is issue slots -- more than the 1.8 % the pass costs.
+//   * P is rounded to e4m3 (v_cvt_pk_fp8_f32) for the second product; with the lazy reference P never exceeds
+//     e^6 = 403 < 448, the largest e4m3 value.  The row sum is taken from the unrounded fp32 p.
 //   * O is written in bf16, L in fp32.  d = 128 only.
 #include <type_traits>
 
@@ -27,15 +32,16 @@
 
 namespace fa2 {
 
+#include "fa2_fwd_fp8_body.inc"
+
 constexpr int kF8Waves = 8;
 constexpr int kF8Rows = 32 * kF8Waves;
-constexpr int kF8KV = 64;
-constexpr int kF8Bufs = 3;
+constexpr int kF8KV = FA2_F8_KV;            // keys per LDS tile (two bodies of 64)
+constexpr int kF8Bufs = FA2_F8_NBUF;
 constexpr int kF8D = 128;
 constexpr float kF8RescaleThr = 6.0f;
 
 typedef __attribute__((address_space(3))) void* f8_lds_ptr_t;
-typedef __attribute__((ext_vector_type(8))) uint32_t u32x8;
 
 #define FA2_F8_CLOBBERS \
     "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", \
@@ -47,14 +53,32 @@ typedef __attribute__((ext_vector_type(8))) uint32_t u32x8;
     "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", \
     "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", \
     "a124", "a125", "a126", "a127"
+// every statement that names a body-owned register: the whole accumulator file and v127 (so that the kernel is allocated all
+// 128 VGPRs: hipcc itself stays below FA2_F8_V0, amdgpu_num_vgpr)
+#define FA2_F8_REGS "v127", FA2_F8_CLOBBERS
+#define FA2_F8_MISC "memory", "vcc", "scc", "s10", "s11", "s12", "m0"
 
-// AGPR map: O^T tile dt: a[16 dt ..+15]; Q fragment of k-step s: a[64 + 8 s ..+7]; packed P: a[80:87]; fragment slot i:
-// a[96 + 8 i ..+7] (K fragments (kb, s) -> slot 2 kb + s in the A stage, V^T fragment dt -> slot dt in
-// the B stage).
 template <int R>
-__device__ __forceinline__ void f8_acc_write(float x)
+__device__ __forceinline__ void f8_vset(uint32_t x)
 {
-    asm volatile("v_accvgpr_write_b32 a[%c1], %0" : : "v"(x), "i"(R) : FA2_F8_CLOBBERS);
+    asm volatile("v_mov_b32 v%c1, %0" : : "v"(x), "i"(R) : FA2_F8_REGS);
+}
+template <int R>
+__device__ __forceinline__ void f8_vsetf(float x)
+{
+    asm volatile("v_mov_b32 v%c1, %0" : : "v"(x), "i"(R) : FA2_F8_REGS);
+}
+template <int R>
+__device__ __forceinline__ float f8_vget()
+{
+    float x;
+    asm volatile("v_mov_b32 %0, v%c1" : "=v"(x) : "i"(R));
+    return x;
+}
+template <int R>
+__device__ __forceinline__ void f8_acc_write(uint32_t x)
+{
+    asm volatile("v_accvgpr_write_b32 a[%c1], %0" : : "v"(x), "i"(R) : FA2_F8_REGS);
 }
 template <int R>
 __device__ __forceinline__ float f8_acc_read()
@@ -73,12 +97,17 @@ __device__ __forceinline__ void f8_acc_scale4(float alpha)
                  "v_accvgpr_write_b32 a[%c5], %0\n\tv_accvgpr_write_b32 a[%c6], %1\n\t"
                  "v_accvgpr_write_b32 a[%c7], %2\n\tv_accvgpr_write_b32 a[%c8], %3"
                  : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
-                 : "v"(alpha), "i"(R), "i"(R + 1), "i"(R + 2), "i"(R + 3) : FA2_F8_CLOBBERS);
+                 : "v"(alpha), "i"(R), "i"(R + 1), "i"(R + 2), "i"(R + 3) : FA2_F8_REGS);
+}
+template <int R>
+__device__ __forceinline__ void f8_acc_zero(u32x4 z)
+{
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[%c1:%c2], %0, %0, 0" : : "v"(z), "i"(R), "i"(R + 15) : FA2_F8_REGS);
 }
 
-// LDS images.  K tile: [64 keys][128 B], 16-byte chunk index XORed with fK(row); V^T tile:
-// [128 d][64 B], chunk index XORed with fV(row).  Both make a 16-lane group of a ds_read_b128 (16
-// different rows, same logical chunk) hit 16 different 16-byte slots of the 256-byte bank row.
+// LDS images.  K tile: [128 keys][128 B], 16-byte chunk index XORed with fK(row); V^T tile: two halves (64 keys each) of
+// [128 d][64 B], chunk index XORed with fV(row).  Both make a 16-lane group of a ds_read_b128 (16 different rows, same
+// logical chunk) hit 16 different 16-byte slots of the 256-byte bank row.
 __device__ __forceinline__ int f8_fk(int row) { return ((row >> 1) & 3) | (((row >> 4) & 1) << 2); }
 __device__ __forceinline__ int f8_fv(int row) { return (row >> 2) & 3; }
 // K row fed as accumulator row m of a 32-key block (see the header): m = 8 j + 4 b + i -> 16 b + 4 j + i.
@@ -108,146 +137,40 @@ __global__ void __launch_bounds__(256) fa2_fp8_transpose_kernel(const unsigned c
     }
 }
 
-// One softmax quad: t0..t3 = exp2(s * c2 - mb); l += t0 + t1 + t2 + t3; w = pack_e4m3(t0, t1, t2, t3).
-#define FA2_F8_QUAD(sa, sb, sc, sd, w)                          \
-    "v_fma_f32 %[t0], %[" sa "], %[c2], -%[mb]\n\t"            \
-    "v_fma_f32 %[t1], %[" sb "], %[c2], -%[mb]\n\t"            \
-    "v_exp_f32 %[t0], %[t0]\n\t"                                \
-    "v_exp_f32 %[t1], %[t1]\n\t"                                \
-    "v_add_f32 %[l], %[l], %[t0]\n\t"                           \
-    "v_cvt_pk_fp8_f32 %[" w "], %[t0], %[t1]\n\t"               \
-    "v_add_f32 %[l], %[l], %[t1]\n\t"                           \
-    "v_fma_f32 %[t0], %[" sc "], %[c2], -%[mb]\n\t"            \
-    "v_fma_f32 %[t1], %[" sd "], %[c2], -%[mb]\n\t"            \
-    "v_exp_f32 %[t0], %[t0]\n\t"                                \
-    "v_exp_f32 %[t1], %[t1]\n\t"                                \
-    "v_add_f32 %[l], %[l], %[t0]\n\t"                           \
-    "v_cvt_pk_fp8_f32 %[" w "], %[t0], %[t1] op_sel:[0,0,1]\n\t" \
-    "v_add_f32 %[l], %[l], %[t1]\n\t"
+struct F8Dma {
+    __amdgpu_buffer_rsrc_t krs, vrs;
+    uint32_t mw, dvk, dvv, kso, vso;
+};
 
-// ---- A stage (asm part): n0, n1 = S^T of the two 32-key blocks of the tile whose K image starts KOFF
-// bytes into LDS; rmax = this lane's maximum over the current tile (sc0, sc1), taken beside the MFMAs.
-template <int KOFF>
-__device__ __forceinline__ void f8_stage_a(f32x16& n0, f32x16& n1, float& rmax, const uint32_t (&ka)[2][2], const f32x16& sc0,
-                                           const f32x16& sc1)
+// One body: half KB of the tile in ring buffer BUF.  KB == 1 starts with the tile barrier and issues the DMA of tile t + 2.
+template <int BUF, int KB, bool MASKED>
+__device__ __forceinline__ void f8_body(float c2, int& need, int hi, const F8Dma& dma)
 {
-    constexpr int HALFK = 32 * kF8D;
-    asm volatile(
-        "ds_read_b128 a[96:99], %[k00] offset:%c[o0]\n\t"
-        "ds_read_b128 a[100:103], %[k01] offset:%c[o0]\n\t"
-        "ds_read_b128 a[104:107], %[k10] offset:%c[o0]\n\t"
-        "ds_read_b128 a[108:111], %[k11] offset:%c[o0]\n\t"
-        "ds_read_b128 a[112:115], %[k00] offset:%c[o1]\n\t"
-        "ds_read_b128 a[116:119], %[k01] offset:%c[o1]\n\t"
-        "ds_read_b128 a[120:123], %[k10] offset:%c[o1]\n\t"
-        "ds_read_b128 a[124:127], %[k11] offset:%c[o1]\n\t"
-        "s_waitcnt lgkmcnt(6)\n\t"
-        "v_mfma_f32_32x32x64_f8f6f4 %[sn], a[96:103], a[64:71], 0\n\t"
-        "v_max3_f32 %[rm], %[s0], %[s1], %[s2]\n\t"
-        "v_max3_f32 %[rm], %[rm], %[s3], %[s4]\n\t"
-        "v_max3_f32 %[rm], %[rm], %[s5], %[s6]\n\t"
-        "v_max3_f32 %[rm], %[rm], %[s7], %[s8]\n\t"
-        "s_waitcnt lgkmcnt(4)\n\t"
-        "v_mfma_f32_32x32x64_f8f6f4 %[sn], a[104:111], a[72:79], %[sn]\n\t"
-        "v_max3_f32 %[rm], %[rm], %[s9], %[s10]\n\t"
-        "v_max3_f32 %[rm], %[rm], %[s11], %[s12]\n\t"
-        "v_max3_f32 %[rm], %[rm], %[s13], %[s14]\n\t"
-        "v_max_f32 %[rm], %[rm], %[s15]"
-        : [sn] "=&v"(n0), [rm] "=&v"(rmax)
-        : [k00] "v"(ka[0][0]), [k01] "v"(ka[0][1]), [k10] "v"(ka[1][0]), [k11] "v"(ka[1][1]), [o0] "i"(KOFF),
-          [o1] "i"(KOFF + HALFK),
-          [s0] "v"(sc0[0]), [s1] "v"(sc0[1]), [s2] "v"(sc0[2]), [s3] "v"(sc0[3]), [s4] "v"(sc0[4]), [s5] "v"(sc0[5]),
-          [s6] "v"(sc0[6]), [s7] "v"(sc0[7]), [s8] "v"(sc0[8]), [s9] "v"(sc0[9]), [s10] "v"(sc0[10]), [s11] "v"(sc0[11]),
-          [s12] "v"(sc0[12]), [s13] "v"(sc0[13]), [s14] "v"(sc0[14]), [s15] "v"(sc0[15])
-        : FA2_F8_CLOBBERS);
-    asm volatile(
-        "s_waitcnt lgkmcnt(2)\n\t"
-        "v_mfma_f32_32x32x64_f8f6f4 %[sn], a[112:119], a[64:71], 0\n\t"
-        "v_max3_f32 %[rm], %[rm], %[s0], %[s1]\n\t"
-        "v_max3_f32 %[rm], %[rm], %[s2], %[s3]\n\t"
-        "v_max3_f32 %[rm], %[rm], %[s4], %[s5]\n\t"
-        "v_max3_f32 %[rm], %[rm], %[s6], %[s7]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_mfma_f32_32x32x64_f8f6f4 %[sn], a[120:127], a[72:79], %[sn]\n\t"
-        "v_max3_f32 %[rm], %[rm], %[s8], %[s9]\n\t"
-        "v_max3_f32 %[rm], %[rm], %[s10], %[s11]\n\t"
-        "v_max3_f32 %[rm], %[rm], %[s12], %[s13]\n\t"
-        "v_max3_f32 %[rm], %[rm], %[s14], %[s15]"
-        : [sn] "=&v"(n1), [rm] "+v"(rmax)
-        : [s0] "v"(sc1[0]), [s1] "v"(sc1[1]), [s2] "v"(sc1[2]), [s3] "v"(sc1[3]), [s4] "v"(sc1[4]), [s5] "v"(sc1[5]),
-          [s6] "v"(sc1[6]), [s7] "v"(sc1[7]), [s8] "v"(sc1[8]), [s9] "v"(sc1[9]), [s10] "v"(sc1[10]), [s11] "v"(sc1[11]),
-          [s12] "v"(sc1[12]), [s13] "v"(sc1[13]), [s14] "v"(sc1[14]), [s15] "v"(sc1[15])
-        : FA2_F8_CLOBBERS);
-}
-
-// ---- B stage: O^T += V^T P^T of the previous tile (V^T image starts VOFF bytes into the V region) with the
-// exponentials, packing and sum of the current tile beside the four MFMAs.
-template <int VOFF>
-__device__ __forceinline__ void f8_stage_b(float& l_run, uint32_t (&pw)[8], const uint32_t (&va)[2], float c2, float mb,
-                                           const f32x16& sc0, const f32x16& sc1)
-{
-    float t0, t1;
-    asm volatile(
-        "ds_read_b128 a[96:99], %[v0] offset:%c[o0]\n\t"
-        "ds_read_b128 a[100:103], %[v1] offset:%c[o0]\n\t"
-        "ds_read_b128 a[104:107], %[v0] offset:%c[o1]\n\t"
-        "ds_read_b128 a[108:111], %[v1] offset:%c[o1]\n\t"
-        "ds_read_b128 a[112:115], %[v0] offset:%c[o2]\n\t"
-        "ds_read_b128 a[116:119], %[v1] offset:%c[o2]\n\t"
-        "ds_read_b128 a[120:123], %[v0] offset:%c[o3]\n\t"
-        "ds_read_b128 a[124:127], %[v1] offset:%c[o3]\n\t"
-        "s_waitcnt lgkmcnt(6)\n\t"
-        "v_mfma_f32_32x32x64_f8f6f4 a[0:15], a[96:103], a[80:87], a[0:15]\n\t"
-        FA2_F8_QUAD("s0", "s1", "s2", "s3", "w0")
-        FA2_F8_QUAD("s4", "s5", "s6", "s7", "w1")
-        : [l] "+v"(l_run), [t0] "=&v"(t0), [t1] "=&v"(t1), [w0] "=&v"(pw[0]), [w1] "=&v"(pw[1])
-        : [v0] "v"(va[0]), [v1] "v"(va[1]), [o0] "i"(VOFF), [o1] "i"(VOFF + 2048), [o2] "i"(VOFF + 4096),
-          [o3] "i"(VOFF + 6144), [c2] "v"(c2), [mb] "v"(mb),
-          [s0] "v"(sc0[0]), [s1] "v"(sc0[1]), [s2] "v"(sc0[2]), [s3] "v"(sc0[3]), [s4] "v"(sc0[4]), [s5] "v"(sc0[5]),
-          [s6] "v"(sc0[6]), [s7] "v"(sc0[7])
-        : FA2_F8_CLOBBERS);
-    asm volatile(
-        "s_waitcnt lgkmcnt(4)\n\t"
-        "v_mfma_f32_32x32x64_f8f6f4 a[16:31], a[104:111], a[80:87], a[16:31]\n\t"
-        FA2_F8_QUAD("s0", "s1", "s2", "s3", "w0")
-        FA2_F8_QUAD("s4", "s5", "s6", "s7", "w1")
-        : [l] "+v"(l_run), [t0] "=&v"(t0), [t1] "=&v"(t1), [w0] "=&v"(pw[2]), [w1] "=&v"(pw[3])
-        : [c2] "v"(c2), [mb] "v"(mb),
-          [s0] "v"(sc0[8]), [s1] "v"(sc0[9]), [s2] "v"(sc0[10]), [s3] "v"(sc0[11]), [s4] "v"(sc0[12]), [s5] "v"(sc0[13]),
-          [s6] "v"(sc0[14]), [s7] "v"(sc0[15])
-        : FA2_F8_CLOBBERS);
-    asm volatile(
-        "s_waitcnt lgkmcnt(2)\n\t"
-        "v_mfma_f32_32x32x64_f8f6f4 a[32:47], a[112:119], a[80:87], a[32:47]\n\t"
-        FA2_F8_QUAD("s0", "s1", "s2", "s3", "w0")
-        FA2_F8_QUAD("s4", "s5", "s6", "s7", "w1")
-        : [l] "+v"(l_run), [t0] "=&v"(t0), [t1] "=&v"(t1), [w0] "=&v"(pw[4]), [w1] "=&v"(pw[5])
-        : [c2] "v"(c2), [mb] "v"(mb),
-          [s0] "v"(sc1[0]), [s1] "v"(sc1[1]), [s2] "v"(sc1[2]), [s3] "v"(sc1[3]), [s4] "v"(sc1[4]), [s5] "v"(sc1[5]),
-          [s6] "v"(sc1[6]), [s7] "v"(sc1[7])
-        : FA2_F8_CLOBBERS);
-    asm volatile(
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_mfma_f32_32x32x64_f8f6f4 a[48:63], a[120:127], a[80:87], a[48:63]\n\t"
-        FA2_F8_QUAD("s0", "s1", "s2", "s3", "w0")
-        FA2_F8_QUAD("s4", "s5", "s6", "s7", "w1")
-        : [l] "+v"(l_run), [t0] "=&v"(t0), [t1] "=&v"(t1), [w0] "=&v"(pw[6]), [w1] "=&v"(pw[7])
-        : [c2] "v"(c2), [mb] "v"(mb),
-          [s0] "v"(sc1[8]), [s1] "v"(sc1[9]), [s2] "v"(sc1[10]), [s3] "v"(sc1[11]), [s4] "v"(sc1[12]), [s5] "v"(sc1[13]),
-          [s6] "v"(sc1[14]), [s7] "v"(sc1[15])
-        : FA2_F8_CLOBBERS);
+#define FA2_F8_CASE(B, K, M)                                                                                                  \
+    if constexpr (BUF == B && KB == K && MASKED == bool(M))                                                                    \
+        asm volatile(FA2_F8_BODY_B##B##_K##K##_M##M                                                                            \
+                     : [need] "=&s"(need)                                                                                      \
+                     : [c2] "s"(c2), [hi] "v"(hi), [ninf] "v"(-INFINITY), [mw] "s"(dma.mw), [dvk] "v"(dma.dvk), [dvv] "v"(dma.dvv), \
+                       [krs] "s"(dma.krs), [vrs] "s"(dma.vrs), [kso] "s"(dma.kso), [vso] "s"(dma.vso)                           \
+                     : FA2_F8_MISC, FA2_F8_REGS);
+#define FA2_F8_CASES(K, M) FA2_F8_CASE(0, K, M) FA2_F8_CASE(1, K, M) FA2_F8_CASE(2, K, M) FA2_F8_CASE(3, K, M)
+    FA2_F8_CASES(0, 0) FA2_F8_CASES(1, 0) FA2_F8_CASES(0, 1) FA2_F8_CASES(1, 1)
+#undef FA2_F8_CASES
+#undef FA2_F8_CASE
 }
 
 template <bool CAUSAL>
-__global__ void __launch_bounds__(64 * kF8Waves, 1) fa2_fwd_fp8_kernel(FwdFp8Args p)
+__global__ void __launch_bounds__(64 * kF8Waves, 1) __attribute__((amdgpu_num_vgpr(FA2_F8_V0))) fa2_fwd_fp8_kernel(FwdFp8Args p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWB = kF8D;                 // bytes per K row
-    constexpr int KT = kF8KV * ROWB;           // K tile: 8 KiB
-    constexpr int VT = kF8D * kF8KV;           // V^T tile: 128 rows of 64 B
-    constexpr int VREG = kF8Bufs * KT;         // LDS: [3 K tiles][3 V^T tiles]
-    constexpr int HALFK = 32 * ROWB;           // second 32-key block of a K tile
+    constexpr int KV = kF8KV, NH = KV / 64;    // keys per tile, bodies per tile
+    constexpr int TILEB = KV * ROWB;           // 16 KiB: K tile; V^T tile = two halves of [128 d][64 B]
+    constexpr int KRING = kF8Bufs * TILEB;     // LDS: [4 K tiles][4 V^T tiles]
     constexpr int DT = kF8D / 32;
+    constexpr int SET0 = FA2_F8_SET0, SET1 = FA2_F8_SET1, PF0 = FA2_F8_PF0, KA = FA2_F8_KA, VA = FA2_F8_VA, ST = FA2_F8_STATE;
+    constexpr int ST_RM = ST + 2, ST_MB = ST + 3, ST_TH = ST + 4, A_QF = FA2_F8_A_QF;
+    static_assert(TILEB == 16384 && NH == 2 && kF8Bufs == 4, "LDS ring as the generator lays it out");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -259,206 +182,217 @@ __global__ void __launch_bounds__(64 * kF8Waves, 1) fa2_fwd_fp8_kernel(FwdFp8Arg
     const int nrb = (N + kF8Rows - 1) / kF8Rows;
     int head, rb;
     map_block(blockIdx.x, p.BH, nrb, head, rb);
-    if (CAUSAL) rb = nrb - 1 - rb;
+    if (CAUSAL) rb = nrb - 1 - rb;            // heaviest row blocks first
 
     const char* Qh = (const char*)p.Q + (size_t)head * N * ROWB;
     const char* Kh = (const char*)p.K + (size_t)head * N * ROWB;
     const char* Vth = (const char*)p.Vt + (size_t)head * kF8D * Npad;
 
-    const int q0 = rb * kF8Rows + wave * 32;
+    const int q0 = rb * kF8Rows + wave * 32;      // first query row of this wave
     const int qrow = q0 + qi;
     const int qld = qrow < N ? qrow : N - 1;
 
-    int ntiles = (N + kF8KV - 1) / kF8KV;
+    // bodies (64 keys) that hold a visible key for some row of the WORKGROUP (the tile barriers need every wave in every
+    // body); two more bodies drain the pipeline (their S^T is masked completely: P = 0)
+    int J = (N + 63) / 64;
     if (CAUSAL) {
-        const int last_q = min(rb * kF8Rows + kF8Rows - 1, N - 1);
-        ntiles = min(ntiles, last_q / kF8KV + 1);
+        const int last_key = min(rb * kF8Rows + kF8Rows - 1, N - 1);
+        J = min(J, last_key / 64 + 1);
     }
-    const int niter = ((ntiles + 1 + 2) / 3) * 3;      // whole triples, at least one (fully masked) tile past the real ones
+    const int JB = J + 2;
 
-    // ---- Q fragments -> AGPRs: k-step s takes bytes 64 s + 32 h .. + 31 of the row
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const u32x4 lo = *reinterpret_cast<const u32x4*>(Qh + (size_t)qld * ROWB + 64 * s + 32 * h);
-        const u32x4 hi = *reinterpret_cast<const u32x4*>(Qh + (size_t)qld * ROWB + 64 * s + 32 * h + 16);
-        if (s == 0)
-            asm volatile("v_accvgpr_write_b32 a64, %0\n\tv_accvgpr_write_b32 a65, %1\n\tv_accvgpr_write_b32 a66, %2\n\t"
-                         "v_accvgpr_write_b32 a67, %3\n\tv_accvgpr_write_b32 a68, %4\n\tv_accvgpr_write_b32 a69, %5\n\t"
-                         "v_accvgpr_write_b32 a70, %6\n\tv_accvgpr_write_b32 a71, %7"
-                         : : "v"(lo[0]), "v"(lo[1]), "v"(lo[2]), "v"(lo[3]), "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3])
-                         : FA2_F8_CLOBBERS);
-        else
-            asm volatile("v_accvgpr_write_b32 a72, %0\n\tv_accvgpr_write_b32 a73, %1\n\tv_accvgpr_write_b32 a74, %2\n\t"
-                         "v_accvgpr_write_b32 a75, %3\n\tv_accvgpr_write_b32 a76, %4\n\tv_accvgpr_write_b32 a77, %5\n\t"
-                         "v_accvgpr_write_b32 a78, %6\n\tv_accvgpr_write_b32 a79, %7"
-                         : : "v"(lo[0]), "v"(lo[1]), "v"(lo[2]), "v"(lo[3]), "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3])
-                         : FA2_F8_CLOBBERS);
-    }
-    static_for<16 * DT>([&](auto R) { f8_acc_write<decltype(R)::value>(0.0f); });
-
-    // ---- running state (see fa2_fwd_bf16.hip)
-    const float inv_scale = 1.0f / p.scale;
-    float m_run = -INFINITY, l_run = 0.0f, mb = 0.0f, thr = -INFINITY;
-
-    // ---- LDS-DMA staging: wave w issues K piece w (rows 8 w .. + 7 of the tile) and V^T piece w (d rows
-    // 16 w .. + 15); the swizzle is applied to the SOURCE chunk, the LDS write is linear.
+    // ---- LDS-DMA staging: the swizzle is applied to the SOURCE chunk, the LDS write is linear.  K piece pc = rows 8 pc .. + 7
+    // of the tile (wave w: pieces w and w + 8); V^T piece (half hf, w) = d rows 16 w .. + 15 of keys 64 hf .. + 63.
     const int krow = lane >> 3, kslot = lane & 7;
     const int doffK = krow * ROWB + 16 * (kslot ^ f8_fk(8 * wave + krow));
     const int vrow = lane >> 2, vslot = lane & 3;
     const int doffV = vrow * Npad + 16 * (vslot ^ f8_fv(vrow));
     const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, N * ROWB, 0x00020000);
     const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vth, 0, kF8D * Npad, 0x00020000);
-    auto stage_k = [&](int t, int slot) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (f8_lds_ptr_t)(smem + slot * KT + wave * 1024), 16, doffK,
-                                                 (t * kF8KV + 8 * wave) * ROWB, 0, 0);
-    };
-    auto stage_v = [&](int t, int slot) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (f8_lds_ptr_t)(smem + VREG + slot * VT + wave * 1024), 16, doffV,
-                                                 16 * wave * Npad + t * kF8KV, 0, 0);
-    };
-
-    const float c2 = p.scale * kLog2e;
-
-    // ---- per-lane LDS addresses.  K fragment (kb, s), half i: row pi(qi) + 32 kb, chunk 4 s + 2 h + i;
-    // V^T fragment dt: row 32 dt + qi, chunks h (keys 16 h ..) and 2 + h (keys 32 + 16 h ..).
-    const uint32_t lbase = (uint32_t)(uintptr_t)smem;
-    const int prow = f8_pi(qi);
-    uint32_t ka[2][2], va[2];
+    auto stage = [&](int t, int buf) {
+        char* b = smem + buf * TILEB + wave * 1024;
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) ka[s][i] = lbase + prow * ROWB + 16 * ((4 * s + 2 * h + i) ^ f8_fk(prow));
-    va[0] = lbase + VREG + qi * 64 + 16 * (h ^ f8_fv(qi));
-    va[1] = lbase + VREG + qi * 64 + 16 * ((2 + h) ^ f8_fv(qi));
-
-    f32x16 sc0, sc1;              // S^T of the current 64-key tile: key blocks 0 and 1
-    // (packed e4m3 P of the previous tile lives in a[80:87]: word j = key block j / 4, registers 4 (j % 4) ..+3)
-    float rmax = -INFINITY;
-
-    // ---- A stage: S^T of the tile whose K image starts KOFF bytes into LDS; rmax = max over sc0, sc1
-    auto stage_a = [&](auto KOFF_, int key0, f32x16& n0, f32x16& n1) {
-        f8_stage_a<decltype(KOFF_)::value>(n0, n1, rmax, ka, sc0, sc1);
-        const bool tail = key0 + kF8KV > N;
-        bool diag = false;
-        if (CAUSAL) diag = key0 + kF8KV - 1 > q0;
-        if (tail || diag) {
-            mfma_vgpr_settle(n1);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int k0 = key0 + 16 * h + r, k1 = k0 + 32;       // register r of half h = key 16 h + r of its block
-                bool d0 = k0 >= N, d1 = k1 >= N;
-                if (CAUSAL) { d0 = d0 || k0 > qrow; d1 = d1 || k1 > qrow; }
-                if (d0) n0[r] = -INFINITY;
-                if (d1) n1[r] = -INFINITY;
-            }
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (f8_lds_ptr_t)(b + i * 8192), 16, doffK, (t * KV + 8 * wave + 64 * i) * ROWB, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (f8_lds_ptr_t)(b + KRING + i * 8192), 16, doffV,
+                                                     16 * wave * Npad + t * KV + 64 * i, 0, 0);
         }
     };
+    stage(0, 0);
+    stage(1, 1);
+    stage(0, 3);          // "the tile before the first": read by the first bodies' P stage (against P = 0): must be finite
 
-    // ---- X stage: lazy softmax reference (fa2_fwd_bf16.hip)
-    float alpha = 1.0f;
-    auto stage_x = [&]() -> bool {
-        bool need = false;
-        if (__any(rmax > thr)) {
+    // ---- Q fragments -> AGPRs: k-step s takes bytes 64 s + 32 h .. + 31 of the row
+    static_for<2>([&](auto S) {
+        constexpr int s = decltype(S)::value;
+        const u32x4 lo = *reinterpret_cast<const u32x4*>(Qh + (size_t)qld * ROWB + 64 * s + 32 * h);
+        const u32x4 hi = *reinterpret_cast<const u32x4*>(Qh + (size_t)qld * ROWB + 64 * s + 32 * h + 16);
+        static_for<4>([&](auto E) {
+            f8_acc_write<A_QF + 8 * s + decltype(E)::value>(lo[decltype(E)::value]);
+            f8_acc_write<A_QF + 8 * s + 4 + decltype(E)::value>(hi[decltype(E)::value]);
+        });
+    });
+    {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        static_for<DT>([&](auto T) { f8_acc_zero<16 * decltype(T)::value>(z); });
+    }
+
+    // ---- running state.  m_run (the reference, natural units) and the deferred O scale are hipcc's; the row sums (two partial
+    // sums), mb = m_run log2 e (0 while -inf) and thr = the raw score above which the lane asks for a new reference live in
+    // the registers the bodies name and are rewritten only by the rare update below.
+    const float inv_scale = 1.0f / p.scale;
+    float m_run = -INFINITY, pend = 1.0f;
+    bool have_pend = false;
+    f8_vsetf<ST>(0.0f);
+    f8_vsetf<ST + 1>(0.0f);
+    f8_vsetf<ST_MB>(0.0f);
+    f8_vsetf<ST_TH>(-INFINITY);
+    // S sets and packed P of "the keys before the first": exp2(-huge) = 0 and P = 0, so the first two bodies add exactly zero
+    static_for<32>([&](auto R) {
+        f8_vsetf<SET0 + decltype(R)::value>(-1.0e30f);
+        f8_vsetf<SET1 + decltype(R)::value>(-1.0e30f);
+    });
+    static_for<16>([&](auto R) { f8_vset<PF0 + decltype(R)::value>(0u); });
+
+    // ---- loop-invariant LDS addresses into the registers the bodies name.  K fragment (blk, s), half i: row pi(qi) + 32 blk
+    // (+ 64 per body), chunk 4 s + 2 h + i; V^T fragment dt: row 32 dt + qi of a half, chunks h (keys 16 h ..) and 2 + h
+    // (keys 32 + 16 h ..).
+    const uint32_t lbase = (uint32_t)(uintptr_t)smem;
+    {
+        const int prow = f8_pi(qi);
+        static_for<4>([&](auto I) {
+            constexpr int s = decltype(I)::value / 2, i = decltype(I)::value % 2;
+            f8_vset<KA + decltype(I)::value>(lbase + prow * ROWB + 16 * ((4 * s + 2 * h + i) ^ f8_fk(prow)));
+        });
+        f8_vset<VA>(lbase + KRING + qi * 64 + 16 * (h ^ f8_fv(qi)));
+        f8_vset<VA + 1>(lbase + KRING + qi * 64 + 16 * ((2 + h) ^ f8_fv(qi)));
+    }
+    const float c2 = p.scale * kLog2e;
+    F8Dma dma;
+    dma.krs = k_rsrc; dma.vrs = v_rsrc;
+    dma.mw = lbase + (uint32_t)wave * 1024u;
+    dma.dvk = (uint32_t)doffK;
+    dma.dvv = (uint32_t)doffV;
+    dma.kso = 0; dma.vso = 0;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                         // tiles 0 and 1 have landed
+    // two waves per SIMD: the later-dispatched half of the workgroup loses every issue arbitration to the older half
+    // (priority, then age); one static priority bump for that half evens them out (MI355X_MICROARCH.md, 'Two waves per SIMD')
+    if (wave >= kF8Waves / 2) __builtin_amdgcn_s_setprio(1);
+    asm volatile(FA2_F8_PRO : : : FA2_F8_MISC, FA2_F8_REGS);
+
+    // ---- the rare path between two bodies: first the O^T rescale left over from the previous update, then a new reference
+    // (fa2_fwd1_bf16.hip: at that point O^T holds the products through the keys j - 2, the row sums through j - 1, and P(j-1)
+    // is packed and waiting: the sums are rescaled at once, O^T one body later)
+    auto update = [&](int need) {
+        if (have_pend) {
+            asm volatile("; fa2-cold: deferred O rescale");
+            mfma_acc_settle();
+            static_for<4 * DT>([&](auto R4) { f8_acc_scale4<4 * decltype(R4)::value>(pend); });
+            pend = 1.0f;
+            have_pend = false;
+        }
+        if (need) {
             asm volatile("; fa2-cold: new softmax reference");
-            const float mx = half_max(rmax) * p.scale;
-            const bool grow = mx > m_run + kF8RescaleThr;
+            const float mx = half_max(f8_vget<ST_RM>()) * p.scale;
+            const bool grow = mx > m_run + kF8RescaleThr;        // also true from m_run = -inf
             const bool any_grow = __any(grow);
             const float m_new = any_grow ? fmaxf(m_run, mx) : m_run;
-            need = any_grow && __any(m_run != -INFINITY && m_new != m_run);
-            alpha = m_new == -INFINITY ? 1.0f : __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);
+            // O only needs scaling if some row already accumulated something at an older reference
+            const bool sc = any_grow && __any(m_run != -INFINITY && m_new != m_run);
+            const float alpha = m_new == -INFINITY ? 1.0f : __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);
             m_run = m_new;
-            mb = m_new == -INFINITY ? 0.0f : m_new * kLog2e;
-            thr = (m_new + kF8RescaleThr) * inv_scale;
-            l_run *= alpha;
+            f8_vsetf<ST_MB>(m_new == -INFINITY ? 0.0f : m_new * kLog2e);      // a row with no visible key yet keeps p = 0
+            f8_vsetf<ST_TH>((m_new + kF8RescaleThr) * inv_scale);
+            f8_vsetf<ST>(f8_vget<ST>() * alpha);
+            f8_vsetf<ST + 1>(f8_vget<ST + 1>() * alpha);
+            pend = sc ? alpha : 1.0f;
+            have_pend = sc;
         }
-        return need;
     };
 
-    // ---- B stage: O^T += V^T P^T of the previous tile (V^T image starts VOFF bytes into the V region) with
-    // the exponentials, packing and sum of the current tile beside the four MFMAs
-    uint32_t pw[8];
-    auto stage_b = [&](auto VOFF_) { f8_stage_b<decltype(VOFF_)::value>(l_run, pw, va, c2, mb, sc0, sc1); };
-
-    // One 64-key step: A(T+1) on K buffer KB, X(T), B(T-1) on V^T buffer VB.
-    auto step = [&](auto KOFF_, int key0, auto VOFF_) {
-        f32x16 n0, n1;
-        stage_a(KOFF_, key0, n0, n1);
-        const bool need = stage_x();
-        stage_b(VOFF_);
-        if (need) {
-            mfma_acc_settle();
-            static_for<4 * DT>([&](auto R4) { f8_acc_scale4<4 * decltype(R4)::value>(alpha); });
-        }
-        // P of this tile becomes the B operand of the next step (a[80:87]); this step's four products were
-        // issued long ago and have read theirs
-        asm volatile("v_accvgpr_write_b32 a80, %0\n\tv_accvgpr_write_b32 a81, %1\n\tv_accvgpr_write_b32 a82, %2\n\t"
-                     "v_accvgpr_write_b32 a83, %3\n\tv_accvgpr_write_b32 a84, %4\n\tv_accvgpr_write_b32 a85, %5\n\t"
-                     "v_accvgpr_write_b32 a86, %6\n\tv_accvgpr_write_b32 a87, %7"
-                     : : "v"(pw[0]), "v"(pw[1]), "v"(pw[2]), "v"(pw[3]), "v"(pw[4]), "v"(pw[5]), "v"(pw[6]), "v"(pw[7])
-                     : FA2_F8_CLOBBERS);
-        sc0 = n0; sc1 = n1;
-    };
-
-    // ---- schedule.  Step T: A on K[T+1], X(T), B on V^T[T-1].  K[t] and V^T[t] live in slots t mod 3 of
-    // their rings.  In front of step T: wait until all but this wave's two newest DMAs have landed (those
-    // of the previous barrier may still be in flight: every tile gets two steps to arrive), barrier, then
-    // request K[T+3] into K[T]'s slot (read for the last time in step T-1) and V^T[T+1] into V^T[T-2]'s.
-    stage_k(0, 0); stage_k(1, 1); stage_k(2, 2);
-    stage_v(0, 0); stage_v(0, 2);          // slot 2 stands in for V^T[-1]: finite data under an all-zero P
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    static_for<8>([&](auto J) { f8_acc_write<80 + decltype(J)::value>(0.0f); });      // P of "tile -1" = 0
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { sc0[r] = 0.0f; sc1[r] = 0.0f; }
-    {
-        f32x16 n0, n1;
-        stage_a(std::integral_constant<int, 0>{}, 0, n0, n1);
-        mfma_vgpr_settle(n1);
-        sc0 = n0; sc1 = n1;
-    }
-    auto tile = [&](auto B_, int T) {
+    // GENERAL = false: both bodies of the tile are known to exist and to be unmasked for this wave (the only code between two
+    // bodies is the test of the flag the body returns); GENERAL = true: tail, diagonal and drain tiles.
+    auto run_tile = [&](auto B_, auto GENERAL_, int t) {
         constexpr int B = decltype(B_)::value;
-        constexpr int B1 = (B + 1) % kF8Bufs, B2 = (B + 2) % kF8Bufs;
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        __syncthreads();
-        stage_k(T + 3, B);
-        stage_v(T + 1, B1);
-        step(std::integral_constant<int, B1 * KT>{}, (T + 1) * kF8KV, std::integral_constant<int, B2 * VT>{});
+        constexpr bool GENERAL = decltype(GENERAL_)::value;
+        dma.kso = (uint32_t)(((t + 2) * KV + 8 * wave) * ROWB);
+        dma.vso = (uint32_t)(16 * wave * Npad + (t + 2) * KV);
+        static_for<NH>([&](auto KB_) {
+            constexpr int kb = decltype(KB_)::value;
+            const int j = t * NH + kb;
+            int need = 0;
+            if constexpr (GENERAL) {
+                if (j >= JB) return;                                  // wave- and workgroup-uniform
+                const int key0 = j * 64;
+                bool masked = key0 + 64 > N;
+                if (CAUSAL) masked = masked || key0 + 63 > q0;
+                if (masked) {
+                    // register r of half h of block blk is key key0 + 32 blk + 16 h + r: alive iff 32 blk + r < hi
+                    const int hi = (CAUSAL ? min(N, qrow + 1) : N) - key0 - 16 * h;
+                    f8_body<B, kb, true>(c2, need, hi, dma);
+                } else {
+                    f8_body<B, kb, false>(c2, need, 0, dma);
+                }
+            } else {
+                f8_body<B, kb, false>(c2, need, 0, dma);
+            }
+            // (both are SGPR values already; the readfirstlane tells hipcc that the branch is uniform)
+            if (__builtin_amdgcn_readfirstlane(need | (int)have_pend)) update(need);
+        });
     };
-    for (int T = 0; T < niter; T += 3) {
-        tile(std::integral_constant<int, 0>{}, T);
-        tile(std::integral_constant<int, 1>{}, T + 1);
-        tile(std::integral_constant<int, 2>{}, T + 2);
+    const int ntl = (JB + NH - 1) / NH;                    // tiles with a body to run (the last one maybe partly)
+    // tiles whose every key is visible to every row of this WAVE: plain bodies, nothing to decide
+    int nfull = N / KV;
+    if (CAUSAL) nfull = min(nfull, (q0 + 1) / KV);
+    nfull = min(nfull, J / NH) & ~3;                       // whole rounds of the ring of four
+    int t = 0;
+    for (; t < nfull; t += 4) {
+        run_tile(std::integral_constant<int, 0>{}, std::false_type{}, t);
+        run_tile(std::integral_constant<int, 1>{}, std::false_type{}, t + 1);
+        run_tile(std::integral_constant<int, 2>{}, std::false_type{}, t + 2);
+        run_tile(std::integral_constant<int, 3>{}, std::false_type{}, t + 3);
     }
+    for (; t < ntl; t += 4) {
+        run_tile(std::integral_constant<int, 0>{}, std::true_type{}, t);
+        if (t + 1 >= ntl) break;
+        run_tile(std::integral_constant<int, 1>{}, std::true_type{}, t + 1);
+        if (t + 2 >= ntl) break;
+        run_tile(std::integral_constant<int, 2>{}, std::true_type{}, t + 2);
+        if (t + 3 >= ntl) break;
+        run_tile(std::integral_constant<int, 3>{}, std::true_type{}, t + 3);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // the last bodies' look-ahead DMA and reads
 
-    // ---- epilogue.  The lane half is recomputed (v_mbcnt) rather than kept from kernel entry: a value that is live
-    // across the whole loop only to be used here gets spilled to scratch at this register budget.
+    // ---- epilogue (as fa2_fwd1_bf16.hip: a lane holds 4 consecutive columns of its row per register quad, its partner lane
+    // (+32) the next 4; one v_permlane32_swap per packed dword pairs them up so that every lane stores 16 contiguous bytes)
     mfma_acc_settle();
-    const int h_ep = (int)(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) >> 5);
-    const float l_tot = half_sum(l_run);
+    const float l_tot = half_sum(f8_vget<ST>() + f8_vget<ST + 1>());
     const size_t qoff = (size_t)head * N + qrow;
-    const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
-    static_for<4 * DT>([&](auto G) {
-        constexpr int dt = decltype(G)::value / 4, g = decltype(G)::value % 4;
-        constexpr int R = dt * 16 + 4 * g;
-        f32x4 v;
-        v[0] = f8_acc_read<R>() * inv; v[1] = f8_acc_read<R + 1>() * inv;
-        v[2] = f8_acc_read<R + 2>() * inv; v[3] = f8_acc_read<R + 3>() * inv;
-        if (qrow < N) {
-            bf16x4 o;
+    const float inv = (l_tot > 0.0f ? 1.0f / l_tot : 0.0f) * pend;      // pend: an O rescale still pending from the last update
+    static_for<2 * DT>([&](auto G) {
+        constexpr int dt = decltype(G)::value / 2, gp = decltype(G)::value % 2;
+        constexpr int R = dt * 16 + 8 * gp;
+        f32x4 v, w;
+        v[0] = f8_acc_read<R>() * inv; v[1] = f8_acc_read<R + 1>() * inv; v[2] = f8_acc_read<R + 2>() * inv; v[3] = f8_acc_read<R + 3>() * inv;
+        w[0] = f8_acc_read<R + 4>() * inv; w[1] = f8_acc_read<R + 5>() * inv; w[2] = f8_acc_read<R + 6>() * inv; w[3] = f8_acc_read<R + 7>() * inv;
+        bf16x4 x, y;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
-            *reinterpret_cast<bf16x4*>((char*)p.O + qoff * (kF8D * 2) + 2 * (32 * dt + 8 * g + 4 * h_ep)) = o;
-        }
+        for (int e = 0; e < 4; ++e) { x[e] = (__bf16)v[e]; y[e] = (__bf16)w[e]; }
+        const u32x2 xu = __builtin_bit_cast(u32x2, x), yu = __builtin_bit_cast(u32x2, y);
+        const auto s0 = __builtin_amdgcn_permlane32_swap(xu[0], yu[0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(xu[1], yu[1], false, false);
+        const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+        if (qrow < N) *reinterpret_cast<u32x4*>((char*)p.O + qoff * (kF8D * 2) + 2 * (32 * dt + 16 * gp + 8 * h)) = o;
     });
-    if (qrow < N && h_ep == 0) p.L[qoff] = m_run + __builtin_logf(l_tot);
+    if (qrow < N && h == 0) p.L[qoff] = m_run + __builtin_logf(l_tot);
 }
-#undef FA2_F8_QUAD
 
 hipError_t launch_fwd_fp8(const FwdFp8Args& a, hipStream_t stream)
 {
-    if (a.d != kF8D) return hipErrorInvalidValue;
-    constexpr int lds = kF8Bufs * (kF8KV * kF8D + kF8D * kF8KV);
+    if (a.d != kF8D || a.Npad % 64 != 0 || a.Npad < a.N) return hipErrorInvalidValue;
+    constexpr int lds = 2 * kF8Bufs * kF8KV * kF8D;
     hipLaunchKernelGGL(fa2_fp8_transpose_kernel, dim3((unsigned)(a.Npad / 64), (unsigned)a.BH), dim3(256), 0, stream,
                        (const unsigned char*)a.V, (unsigned char*)a.Vt, a.N, a.Npad);
     hipError_t e = hipGetLastError();

@@ -22,11 +22,14 @@ def body(text, name):
 
 
 def regs(tok):
-    m = re.match(r"v\[(\d+):(\d+)\]", tok)
+    """Register numbers a token names: v<n> -> n, a<n> -> 1000 + n (accumulator registers matter where LDS reads deliver
+    fragments into them: the fp8 forward's slots)."""
+    m = re.match(r"([va])\[(\d+):(\d+)\]", tok)
     if m:
-        return set(range(int(m.group(1)), int(m.group(2)) + 1))
-    m = re.match(r"v(\d+)$", tok)
-    return {int(m.group(1))} if m else set()
+        base = 1000 if m.group(1) == "a" else 0
+        return set(range(base + int(m.group(2)), base + int(m.group(3)) + 1))
+    m = re.match(r"([va])(\d+)$", tok)
+    return {(1000 if m.group(1) == "a" else 0) + int(m.group(2))} if m else set()
 
 
 def check(lines, label):
