@@ -150,7 +150,7 @@ size_t fa2_forward_fp8_workspace_bytes(int B, int H, int seq_len, int head_dim)
 {
     if (B <= 0 || H <= 0 || seq_len <= 0 || head_dim != 128) return 0;
     const size_t npad = ((size_t)seq_len + 63) / 64 * 64;
-    return (size_t)B * H * head_dim * npad;
+    return (size_t)B * H * head_dim * npad + (size_t)B * H * (npad / 64) * sizeof(float);      // V^T | key-norm maxima (npad % 64 == 0: aligned)
 }
 
 int fa2_forward_fp8(const void* Q, const void* K, const void* V, void* O, float* L,
@@ -166,6 +166,7 @@ int fa2_forward_fp8(const void* Q, const void* K, const void* V, void* O, float*
     fa2::FwdFp8Args a{};
     a.Q = Q; a.K = K; a.V = V; a.Vt = workspace; a.O = O; a.L = L;
     a.BH = B * H; a.N = seq_len; a.Npad = (seq_len + 63) / 64 * 64; a.d = head_dim;
+    a.kn = reinterpret_cast<float*>((char*)workspace + (size_t)a.BH * head_dim * a.Npad);
     a.scale = softmax_scale; a.causal = causal ? 1 : 0;
     return hip_status(fa2::launch_fwd_fp8(a, (hipStream_t)stream));
 }

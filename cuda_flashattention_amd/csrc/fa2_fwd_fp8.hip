@@ -25,6 +25,14 @@
 //   * P is rounded to e4m3 (v_cvt_pk_fp8_f32) for the second product; with the lazy reference P never exceeds
 //     e^6 = 403 < 448, the largest e4m3 value.  The row sum is taken from the unrounded fp32 p.
 //   * O is written in bf16, L in fp32.  d = 128 only.
+//
+// Lane maxima only where they can matter.  The online softmax needs a row's maximum over new keys only to notice that a score
+// passes the row's threshold (reference + 6).  By Cauchy-Schwarz scale q.k <= scale |q| |k|: the pre-pass that transposes V also
+// writes, per 64 keys, the largest |k| (kn), a wave knows the largest scale |q| of its 32 rows (qn) and the smallest reference
+// among them (m_min, refreshed by the rare update); for a round of the LDS ring (512 keys) with qn max(kn) <= m_min + 6 no
+// score can pass any threshold, and the wave runs the X variant of the bodies: no v_max3 (16 of a body's 130 VALU
+// instructions), no compare.  Same bits as with the maxima -- they would have triggered nothing.  Keys with an outlier norm,
+// the first round (no reference yet), the sequence tail and the causal diagonal run the bodies with maxima.
 #include <type_traits>
 
 #include "fa2_common.h"
@@ -105,6 +113,12 @@ __device__ __forceinline__ void f8_acc_zero(u32x4 z)
     asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[%c1:%c2], %0, %0, 0" : : "v"(z), "i"(R), "i"(R + 15) : FA2_F8_REGS);
 }
 
+// a wave-uniform float into an SGPR (the builtin is typed int: the value goes through it as bits)
+__device__ __forceinline__ float f8_uniform(float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
+}
+
 // LDS images.  K tile: [128 keys][128 B], 16-byte chunk index XORed with fK(row); V^T tile: two halves (64 keys each) of
 // [128 d][64 B], chunk index XORed with fV(row).  Both make a 16-lane group of a ds_read_b128 (16 different rows, same
 // logical chunk) hit 16 different 16-byte slots of the 256-byte bank row.
@@ -113,11 +127,35 @@ __device__ __forceinline__ int f8_fv(int row) { return (row >> 2) & 3; }
 // K row fed as accumulator row m of a 32-key block (see the header): m = 8 j + 4 b + i -> 16 b + 4 j + i.
 __device__ __forceinline__ int f8_pi(int m) { return (m & 3) + 4 * ((m >> 3) & 3) + 16 * ((m >> 2) & 1); }
 
-// ---- V [N][128] -> V^T [128][Npad] per head (keys >= N written as zeros)
-__global__ void __launch_bounds__(256) fa2_fp8_transpose_kernel(const unsigned char* V, unsigned char* Vt, int N, int Npad)
+// ---- pre-pass, one block per 64 keys of a head: V [N][128] -> V^T [128][Npad] (keys >= N written as zeros), and
+// kn[head][block] = the largest |k| among the block's keys, rounded up (see the header)
+__global__ void __launch_bounds__(256) fa2_fp8_transpose_kernel(const unsigned char* V, unsigned char* Vt, const unsigned char* K, float* kn,
+                                                                int N, int Npad)
 {
     __shared__ unsigned char tile[64][kF8D + 4];
+    __shared__ float wmax[4];
     const int head = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
+    {   // four lanes per key: 32 bytes each
+        const int key = t * 64 + (tid >> 2);
+        float ss = 0.0f;
+        if (key < N) {
+            const u32x4* kp = reinterpret_cast<const u32x4*>(K + ((size_t)head * N + key) * kF8D + 32 * (tid & 3));
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const u32x4 w = kp[c];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const auto lo = __builtin_amdgcn_cvt_pk_f32_fp8(w[e], false), hi = __builtin_amdgcn_cvt_pk_f32_fp8(w[e], true);
+                    ss += lo[0] * lo[0] + lo[1] * lo[1] + hi[0] * hi[0] + hi[1] * hi[1];
+                }
+            }
+        }
+        ss += __shfl_xor(ss, 1);
+        ss += __shfl_xor(ss, 2);
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) ss = fmaxf(ss, __shfl_xor(ss, o));
+        if ((tid & 63) == 0) wmax[tid >> 6] = ss;
+    }
     const unsigned char* Vh = V + (size_t)head * N * kF8D;
     unsigned char* Vth = Vt + (size_t)head * kF8D * Npad;
     for (int c = tid; c < 64 * (kF8D / 4); c += 256) {
@@ -135,6 +173,8 @@ __global__ void __launch_bounds__(256) fa2_fp8_transpose_kernel(const unsigned c
         for (int e = 0; e < 4; ++e) v |= (uint32_t)tile[4 * w + e][dcol] << (8 * e);
         *reinterpret_cast<uint32_t*>(Vth + (size_t)dcol * Npad + t * 64 + 4 * w) = v;
     }
+    if (tid == 0)
+        kn[(size_t)head * (Npad / 64) + t] = __builtin_sqrtf(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))) * 1.0002f;
 }
 
 struct F8Dma {
@@ -143,18 +183,20 @@ struct F8Dma {
 };
 
 // One body: half KB of the tile in ring buffer BUF.  KB == 1 starts with the tile barrier and issues the DMA of tile t + 2.
-template <int BUF, int KB, bool MASKED>
+enum { F8_PLAIN = 0, F8_MASKED = 1, F8_NOMAX = 2 };
+template <int BUF, int KB, int MODE>
 __device__ __forceinline__ void f8_body(float c2, int& need, int hi, const F8Dma& dma)
 {
-#define FA2_F8_CASE(B, K, M)                                                                                                  \
-    if constexpr (BUF == B && KB == K && MASKED == bool(M))                                                                    \
-        asm volatile(FA2_F8_BODY_B##B##_K##K##_M##M                                                                            \
+#define FA2_F8_CASE(B, K, MV, M)                                                                                              \
+    if constexpr (BUF == B && KB == K && MODE == MV)                                                                           \
+        asm volatile(FA2_F8_BODY_B##B##_K##K##_##M                                                                             \
                      : [need] "=&s"(need)                                                                                      \
                      : [c2] "s"(c2), [hi] "v"(hi), [ninf] "v"(-INFINITY), [mw] "s"(dma.mw), [dvk] "v"(dma.dvk), [dvv] "v"(dma.dvv), \
                        [krs] "s"(dma.krs), [vrs] "s"(dma.vrs), [kso] "s"(dma.kso), [vso] "s"(dma.vso)                           \
                      : FA2_F8_MISC, FA2_F8_REGS);
-#define FA2_F8_CASES(K, M) FA2_F8_CASE(0, K, M) FA2_F8_CASE(1, K, M) FA2_F8_CASE(2, K, M) FA2_F8_CASE(3, K, M)
-    FA2_F8_CASES(0, 0) FA2_F8_CASES(1, 0) FA2_F8_CASES(0, 1) FA2_F8_CASES(1, 1)
+#define FA2_F8_CASES(K, MV, M) FA2_F8_CASE(0, K, MV, M) FA2_F8_CASE(1, K, MV, M) FA2_F8_CASE(2, K, MV, M) FA2_F8_CASE(3, K, MV, M)
+    FA2_F8_CASES(0, F8_PLAIN, M0) FA2_F8_CASES(1, F8_PLAIN, M0) FA2_F8_CASES(0, F8_MASKED, M1) FA2_F8_CASES(1, F8_MASKED, M1)
+    FA2_F8_CASES(0, F8_NOMAX, X) FA2_F8_CASES(1, F8_NOMAX, X)
 #undef FA2_F8_CASES
 #undef FA2_F8_CASE
 }
@@ -223,15 +265,26 @@ __global__ void __launch_bounds__(64 * kF8Waves, 1) __attribute__((amdgpu_num_vg
     stage(0, 3);          // "the tile before the first": read by the first bodies' P stage (against P = 0): must be finite
 
     // ---- Q fragments -> AGPRs: k-step s takes bytes 64 s + 32 h .. + 31 of the row
+    // (on the way: qn = the largest scale |q| among the wave's rows, rounded up -- see the header)
+    float qss = 0.0f;
     static_for<2>([&](auto S) {
         constexpr int s = decltype(S)::value;
         const u32x4 lo = *reinterpret_cast<const u32x4*>(Qh + (size_t)qld * ROWB + 64 * s + 32 * h);
         const u32x4 hi = *reinterpret_cast<const u32x4*>(Qh + (size_t)qld * ROWB + 64 * s + 32 * h + 16);
         static_for<4>([&](auto E) {
-            f8_acc_write<A_QF + 8 * s + decltype(E)::value>(lo[decltype(E)::value]);
-            f8_acc_write<A_QF + 8 * s + 4 + decltype(E)::value>(hi[decltype(E)::value]);
+            constexpr int e = decltype(E)::value;
+            f8_acc_write<A_QF + 8 * s + e>(lo[e]);
+            f8_acc_write<A_QF + 8 * s + 4 + e>(hi[e]);
+            const auto a = __builtin_amdgcn_cvt_pk_f32_fp8(lo[e], false), b = __builtin_amdgcn_cvt_pk_f32_fp8(lo[e], true);
+            const auto c = __builtin_amdgcn_cvt_pk_f32_fp8(hi[e], false), d = __builtin_amdgcn_cvt_pk_f32_fp8(hi[e], true);
+            qss += a[0] * a[0] + a[1] * a[1] + b[0] * b[0] + b[1] * b[1] + c[0] * c[0] + c[1] * c[1] + d[0] * d[0] + d[1] * d[1];
         });
     });
+    qss = half_sum(qss);                              // the two lane halves hold the two halves of each 64-byte k-step
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) qss = fmaxf(qss, __shfl_xor(qss, o));
+    const float qn = f8_uniform(__builtin_sqrtf(qss) * p.scale * 1.0002f);
+    const float* knh = p.kn + (size_t)head * (Npad / 64);
     {
         const u32x4 z = {0u, 0u, 0u, 0u};
         static_for<DT>([&](auto T) { f8_acc_zero<16 * decltype(T)::value>(z); });
@@ -242,6 +295,7 @@ __global__ void __launch_bounds__(64 * kF8Waves, 1) __attribute__((amdgpu_num_vg
     // the registers the bodies name and are rewritten only by the rare update below.
     const float inv_scale = 1.0f / p.scale;
     float m_run = -INFINITY, pend = 1.0f;
+    float m_min6 = -INFINITY;             // wave-uniform: the smallest threshold (reference + 6, natural units) among the wave's rows
     bool have_pend = false;
     f8_vsetf<ST>(0.0f);
     f8_vsetf<ST + 1>(0.0f);
@@ -279,7 +333,9 @@ __global__ void __launch_bounds__(64 * kF8Waves, 1) __attribute__((amdgpu_num_vg
     __syncthreads();                         // tiles 0 and 1 have landed
     // two waves per SIMD: the later-dispatched half of the workgroup loses every issue arbitration to the older half
     // (priority, then age); one static priority bump for that half evens them out (MI355X_MICROARCH.md, 'Two waves per SIMD')
+#ifndef FA2_F8_NO_SETPRIO
     if (wave >= kF8Waves / 2) __builtin_amdgcn_s_setprio(1);
+#endif
     asm volatile(FA2_F8_PRO : : : FA2_F8_MISC, FA2_F8_REGS);
 
     // ---- the rare path between two bodies: first the O^T rescale left over from the previous update, then a new reference
@@ -309,14 +365,20 @@ __global__ void __launch_bounds__(64 * kF8Waves, 1) __attribute__((amdgpu_num_vg
             f8_vsetf<ST + 1>(f8_vget<ST + 1>() * alpha);
             pend = sc ? alpha : 1.0f;
             have_pend = sc;
+            float mm = m_new;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) mm = fminf(mm, __shfl_xor(mm, o));
+            m_min6 = f8_uniform(mm) + kF8RescaleThr;
         }
     };
 
-    // GENERAL = false: both bodies of the tile are known to exist and to be unmasked for this wave (the only code between two
-    // bodies is the test of the flag the body returns); GENERAL = true: tail, diagonal and drain tiles.
-    auto run_tile = [&](auto B_, auto GENERAL_, int t) {
+    // FLAVOUR 0 / 2: both bodies of the tile are known to exist and to be unmasked for this wave (the only code between two
+    // bodies is the test of the flag the body returns), with (0) or without (2) the lane maxima; 1: GENERAL -- tail, diagonal
+    // and drain tiles.
+    auto run_tile = [&](auto B_, auto FLAVOUR_, int t) {
         constexpr int B = decltype(B_)::value;
-        constexpr bool GENERAL = decltype(GENERAL_)::value;
+        constexpr bool GENERAL = decltype(FLAVOUR_)::value == 1;
+        constexpr int FAST = decltype(FLAVOUR_)::value == 2 ? F8_NOMAX : F8_PLAIN;
         dma.kso = (uint32_t)(((t + 2) * KV + 8 * wave) * ROWB);
         dma.vso = (uint32_t)(16 * wave * Npad + (t + 2) * KV);
         static_for<NH>([&](auto KB_) {
@@ -331,12 +393,12 @@ __global__ void __launch_bounds__(64 * kF8Waves, 1) __attribute__((amdgpu_num_vg
                 if (masked) {
                     // register r of half h of block blk is key key0 + 32 blk + 16 h + r: alive iff 32 blk + r < hi
                     const int hi = (CAUSAL ? min(N, qrow + 1) : N) - key0 - 16 * h;
-                    f8_body<B, kb, true>(c2, need, hi, dma);
+                    f8_body<B, kb, F8_MASKED>(c2, need, hi, dma);
                 } else {
-                    f8_body<B, kb, false>(c2, need, 0, dma);
+                    f8_body<B, kb, F8_PLAIN>(c2, need, 0, dma);
                 }
             } else {
-                f8_body<B, kb, false>(c2, need, 0, dma);
+                f8_body<B, kb, FAST>(c2, need, 0, dma);
             }
             // (both are SGPR values already; the readfirstlane tells hipcc that the branch is uniform)
             if (__builtin_amdgcn_readfirstlane(need | (int)have_pend)) update(need);
@@ -347,21 +409,31 @@ __global__ void __launch_bounds__(64 * kF8Waves, 1) __attribute__((amdgpu_num_vg
     int nfull = N / KV;
     if (CAUSAL) nfull = min(nfull, (q0 + 1) / KV);
     nfull = min(nfull, J / NH) & ~3;                       // whole rounds of the ring of four
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
     int t = 0;
     for (; t < nfull; t += 4) {
-        run_tile(std::integral_constant<int, 0>{}, std::false_type{}, t);
-        run_tile(std::integral_constant<int, 1>{}, std::false_type{}, t + 1);
-        run_tile(std::integral_constant<int, 2>{}, std::false_type{}, t + 2);
-        run_tile(std::integral_constant<int, 3>{}, std::false_type{}, t + 3);
+        // one round of the ring = 512 keys = 8 entries of kn: can any of their scores pass any row's threshold?
+        float kmax = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) kmax = fmaxf(kmax, knh[2 * t + i]);
+#ifdef FA2_F8_FORCE_MAX
+        kmax = INFINITY;
+#endif
+        if (qn * kmax <= m_min6) {
+            run_tile(I0{}, I2{}, t); run_tile(I1{}, I2{}, t + 1); run_tile(I2{}, I2{}, t + 2); run_tile(I3{}, I2{}, t + 3);
+        } else {
+            run_tile(I0{}, I0{}, t); run_tile(I1{}, I0{}, t + 1); run_tile(I2{}, I0{}, t + 2); run_tile(I3{}, I0{}, t + 3);
+        }
     }
     for (; t < ntl; t += 4) {
-        run_tile(std::integral_constant<int, 0>{}, std::true_type{}, t);
+        run_tile(I0{}, I1{}, t);
         if (t + 1 >= ntl) break;
-        run_tile(std::integral_constant<int, 1>{}, std::true_type{}, t + 1);
+        run_tile(I1{}, I1{}, t + 1);
         if (t + 2 >= ntl) break;
-        run_tile(std::integral_constant<int, 2>{}, std::true_type{}, t + 2);
+        run_tile(I2{}, I1{}, t + 2);
         if (t + 3 >= ntl) break;
-        run_tile(std::integral_constant<int, 3>{}, std::true_type{}, t + 3);
+        run_tile(I3{}, I1{}, t + 3);
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // the last bodies' look-ahead DMA and reads
 
@@ -391,10 +463,10 @@ __global__ void __launch_bounds__(64 * kF8Waves, 1) __attribute__((amdgpu_num_vg
 
 hipError_t launch_fwd_fp8(const FwdFp8Args& a, hipStream_t stream)
 {
-    if (a.d != kF8D || a.Npad % 64 != 0 || a.Npad < a.N) return hipErrorInvalidValue;
+    if (a.d != kF8D || a.Npad % 64 != 0 || a.Npad < a.N || !a.kn) return hipErrorInvalidValue;
     constexpr int lds = 2 * kF8Bufs * kF8KV * kF8D;
     hipLaunchKernelGGL(fa2_fp8_transpose_kernel, dim3((unsigned)(a.Npad / 64), (unsigned)a.BH), dim3(256), 0, stream,
-                       (const unsigned char*)a.V, (unsigned char*)a.Vt, a.N, a.Npad);
+                       (const unsigned char*)a.V, (unsigned char*)a.Vt, (const unsigned char*)a.K, a.kn, a.N, a.Npad);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int nrb = (a.N + kF8Rows - 1) / kF8Rows;

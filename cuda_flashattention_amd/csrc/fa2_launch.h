@@ -36,10 +36,12 @@ hipError_t launch_accumulate_bf16(float* acc, const void* src, size_t rows, size
 hipError_t launch_finalize_state(const float* Oacc, const float* M, float* L, void* O, size_t rows, int d, hipStream_t stream);
 
 // fp8 (OCP e4m3) forward, d = 128: Q, K, V fp8 [BH][N][128]; O bf16; Vt: [BH][128][Npad] fp8 scratch the
-// launcher fills with V transposed (Npad = N rounded up to 64).
+// launcher fills with V transposed (Npad = N rounded up to 64); kn: [BH][Npad / 64] fp32 scratch it fills with the largest
+// |k| of every 64 keys (fa2_fwd_fp8.hip: where the softmax needs no lane maxima).
 struct FwdFp8Args {
     const void* Q; const void* K; const void* V;
     void* Vt;
+    float* kn;
     void* O;
     float* L;
     int BH, N, Npad, d;

@@ -92,7 +92,9 @@ int fa2_forward(const void* Q, const void* K, const void* V, void* O, float* L,
 
 /* fp8 (OCP e4m3) forward, BASELINE configs[4]: Q, K, V are e4m3 [B][H][N][128], O is bf16, L fp32.  The
  * kernel reads V through a transposed copy ([B][H][128][N rounded up to 64], e4m3) that this call writes
- * into `workspace` first (fa2_forward_fp8_workspace_bytes).  fa2_forward(..., FA2_DTYPE_FP8_E4M3, ...) is
+ * into `workspace` first, followed by the largest key norm of every 64 keys ([B][H][N / 64] fp32: where scale |q| |k|
+ * cannot reach a row's rescale threshold the kernel skips that row's running-maximum update -- same results)
+ * (fa2_forward_fp8_workspace_bytes).  fa2_forward(..., FA2_DTYPE_FP8_E4M3, ...) is
  * the same call with the workspace taken from the stream-ordered allocator.  No counterpart in the
  * reference (fp32 end to end): parity is against the oracle fed the e4m3-rounded inputs. */
 size_t fa2_forward_fp8_workspace_bytes(int B, int H, int seq_len, int head_dim);

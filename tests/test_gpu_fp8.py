@@ -79,6 +79,29 @@ def test_fwd_fp8_rescale_branch_forced():
     assert np.abs(L.cpu().numpy() - Lr).max() <= 1e-3
 
 
+@pytest.mark.parametrize("causal", [False, True])
+def test_fwd_fp8_rounds_without_lane_maxima_and_an_outlier_round(causal):
+    """The kernel skips the lane maxima for a round of the LDS ring (512 keys) when scale |q| |k| cannot pass any row's
+    threshold (fa2_fwd_fp8.hip).  N = 4096: round 0 has no reference yet (maxima), the ordinary rounds run without them, and
+    the rounds that hold an outlier key (|k| x 30: a late key that dominates its row, and a key of large norm that is
+    orthogonal to every query) must run with them -- all against the oracle, L to 1e-3 as in the forced-rescale case."""
+    fa, oracle = _fa(), _oracle()
+    B, H, N, d = 1, 2, 4096, 128
+    Q, K, V = make(B, H, N, d, 21), make(B, H, N, d, 22), make(B, H, N, d, 23)
+    Kf = K.float()
+    Kf[0, 0, 2900] = Q.float()[0, 0, 3500] * 30.0           # round 5 (keys 2560 .. 3071): visible to row 3500 under the mask too
+    Kf[0, 1, 1700] = torch.sign(Kf[0, 1, 1700]) * 4.0       # large norm (45), scores that stay below every threshold
+    K = Kf.to(torch.float8_e4m3fn)
+    s = 1.0 / d ** 0.5
+    O, L = fa.flash_attention_2_forward(Q.cuda(), K.cuda(), V.cuda(), s, causal=causal)
+    torch.cuda.synchronize()
+    Or, Lr = oracle.attention_forward(f32(Q), f32(K), f32(V), s, causal=causal)
+    assert np.isfinite(f32(O)).all()
+    assert rel(f32(O), Or) <= FP8_REL
+    assert np.abs(L.cpu().numpy() - Lr).max() <= 1e-3
+    assert np.abs(L.cpu().numpy()[0, 1] - Lr[0, 1]).max() <= 1e-4          # no row of this head moved its reference late
+
+
 def test_fwd_fp8_explicit_workspace_and_properties():
     """fa2_forward_fp8 with a caller workspace equals fa2_forward(dtype = fp8); at the BASELINE configs[4]
     row length rows of O are convex combinations of V rows (size-independent property)."""
@@ -88,7 +111,7 @@ def test_fwd_fp8_explicit_workspace_and_properties():
     Q, K, V = (make(B, H, N, d, s).cuda() for s in (5, 6, 7))
     O1, L1 = fa.flash_attention_2_forward(Q, K, V, None, causal=True)
     need = lib.fa2_forward_fp8_workspace_bytes(B, H, N, d)
-    assert need == B * H * d * N
+    assert need == B * H * d * N + B * H * (N // 64) * 4          # V^T | largest |k| of every 64 keys
     ws = torch.empty(need, dtype=torch.uint8, device="cuda")
     O2 = torch.empty_like(O1)
     L2 = torch.empty_like(L1)

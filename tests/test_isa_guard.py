@@ -249,7 +249,40 @@ def test_fp8_loop_budget(asm):
             assert any("v_mfma_f32_32x32x64_f8f6f4" in l for l in _main_loop(k["body"]))
 
 
-@pytest.mark.parametrize("inc", ["fa2_bwd_dkdv_body.inc", "fa2_bwd_dq_body.inc", "fa2_bwd_fused_body.inc", "fa2_fwd_body.inc"])
+def test_generated_fp8_forward_kernel(asm):
+    """The fp8 forward (csrc/fa2_fwd_fp8.hip, bodies from tools/gen_fwd_fp8_body.py): two waves per SIMD, amdgpu_num_vgpr(32),
+    128 + 128 registers.  Per ring buffer and half of a tile there is a plain, a masked and a no-maxima body with 8 MFMAs
+    (v_mfma_f32_32x32x64_f8f6f4); the bodies of a tile's second half open with vmcnt(0) + s_barrier and carry the wave's four
+    LDS-DMA pieces of the tile two ahead; nothing outside the asm regions names a body register or an accumulator."""
+    ks = {n: k for n, k in _kernels(asm["fa2_fwd_fp8"]).items() if "fa2_fwd_fp8_kernel" in n}
+    assert len(ks) == 2           # causal or not
+    pat = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+    for name, k in ks.items():
+        outside, blocks = _split_asm(k["body"])
+        for s in outside:
+            for m in pat.finditer(s):
+                hi = int(m.group(1)) if m.group(1) else int(m.group(3))
+                assert hi < 32, (name, s)
+        hits = [s for s in outside if re.search(r"v_accvgpr|\ba\[\d+|\ba\d+\b", s)]
+        assert not hits, (name, hits[:5])
+        assert k["meta"]["scratch"] == 0 and k["meta"]["vgpr_spill"] == 0 and k["meta"]["total"] == 256, (name, k["meta"])
+        bodies = [b for b in blocks if sum("v_mfma_f32_32x32x64_f8f6f4" in s for s in b) == 8 and len(b) > 100]
+        # per ring buffer and half: the round with maxima, the round without, and the general loop's plain + masked bodies
+        assert len(bodies) == 4 * 2 * 4, (name, len(bodies))
+        with_barrier = [b for b in bodies if any(s.startswith("s_barrier") for s in b)]
+        assert len(with_barrier) == 16            # one per tile
+        for b in with_barrier:
+            assert b[0].startswith("s_waitcnt vmcnt(0)") and b[1].startswith("s_barrier")
+            assert sum(s.startswith("buffer_load_dwordx4") and s.endswith(" lds") for s in b) == 4
+        for b in bodies:
+            if b not in with_barrier:
+                assert not any("buffer_load" in s for s in b)
+        assert sum(any(s.startswith("v_cndmask_b32") for s in b) for b in bodies) == 8       # the masked variants
+        assert sum(not any(s.startswith("v_max3_f32") for s in b) for b in bodies) == 8      # the no-maxima variants
+
+
+@pytest.mark.parametrize("inc", ["fa2_bwd_dkdv_body.inc", "fa2_bwd_dq_body.inc", "fa2_bwd_fused_body.inc", "fa2_fwd_body.inc",
+                                 "fa2_fwd_fp8_body.inc"])
 def test_generated_bodies_pass_the_static_checker(inc):
     """tools/check_body.py replays every generated main-loop body twice in a row (steady state) with an in-order model of
     the LDS queue: each MFMA source delivered by an LDS read is covered by a counted lgkmcnt, no read overwrites a
@@ -261,7 +294,7 @@ def test_generated_bodies_pass_the_static_checker(inc):
     spec.loader.exec_module(cb)
     text = open(os.path.join(CSRC, inc)).read()
     names = re.findall(r"#define (FA2_\w+_[CM]?BODY_\w+) ", text)
-    assert len(names) in (12, 16, 18, 80)
+    assert len(names) in (12, 16, 18, 24, 80)
     for n in names:
         assert cb.check(cb.body(text, n), n) == []
 
@@ -269,7 +302,8 @@ def test_generated_bodies_pass_the_static_checker(inc):
 def test_generated_bodies_are_up_to_date(tmp_path):
     """The committed .inc files are what the generators produce (nobody edits them by hand, nobody forgets to regenerate)."""
     for gen, inc in (("gen_dkdv_body.py", "fa2_bwd_dkdv_body.inc"), ("gen_dq_body.py", "fa2_bwd_dq_body.inc"),
-                     ("gen_fused_body.py", "fa2_bwd_fused_body.inc"), ("gen_fwd_body.py", "fa2_fwd_body.inc")):
+                     ("gen_fused_body.py", "fa2_bwd_fused_body.inc"), ("gen_fwd_body.py", "fa2_fwd_body.inc"),
+                     ("gen_fwd_fp8_body.py", "fa2_fwd_fp8_body.inc")):
         out = tmp_path / inc
         subprocess.check_call(["python3", os.path.join(ROOT, "tools", gen), "--out", str(out)], cwd=os.path.join(ROOT, "tools"),
                               stdout=subprocess.DEVNULL)

@@ -42,6 +42,8 @@ from gen_dkdv_body import Task
 READ_AHEAD = int(os.environ.get("FA2_GEN_F8_READ_AHEAD", "4"))
 READ_LATEST = int(os.environ.get("FA2_GEN_F8_READ_LATEST", "2"))
 BUDGET = int(os.environ.get("FA2_GEN_F8_BUDGET", "96"))
+ORDER = int(os.environ.get("FA2_GEN_F8_ORDER", "0"))       # 0: A A A A P P P P; 1: A A P P A A P P
+WIN = int(os.environ.get("FA2_GEN_F8_WIN", "1"))           # half-width (gaps) of a softmax quad's window
 NBUF = 4
 D = 128
 ROWB = 128                    # bytes per K row
@@ -82,10 +84,16 @@ def qf(s): b = A_QF + 8 * s; return f"a[{b}:{b + 7}]"
 def o(dt): b = A_O + 16 * dt; return f"a[{b}:{b + 15}]"
 
 
-def build(par, masked, dma):
+def build(par, masked, dma, nomax=False):
     """One body of parity `par`.  Gap units 0 .. NS-1; tasks with a negative release belong to the tail of the previous body
     (emitted there with the NEXT body's bases: '@N')."""
-    gP = 2 * KS
+    # gap of A product (blk, s) and of P product dt
+    if ORDER == 0:
+        gA = lambda blk, s: KS * blk + s
+        gPd = lambda dt: 2 * KS + dt
+    else:
+        gA = lambda blk, s: 4 * blk + s
+        gPd = lambda dt: 2 + 4 * (dt // 2) + dt % 2
     mfma = [None] * NS
     tasks = []
     ctr = [0]
@@ -103,9 +111,18 @@ def build(par, masked, dma):
         tasks.append(Task(text, COST["lds"], rel, max(consume - READ_LATEST, rel), "lds", key))
 
     def allocate(rec):
-        for blk in (0, 1):
-            for s in range(KS):
-                g = KS * blk + s
+        for g in range(NS):
+            for blk in (0, 1):
+                for s in range(KS):
+                    if gA(blk, s) == g:
+                        alloc_a(rec, blk, s, g)
+            for dt in range(DT):
+                if gPd(dt) == g:
+                    alloc_p(rec, dt, g)
+
+    def alloc_a(rec, blk, s, g):
+        if True:
+            if True:
                 sk, fk = take(g)
                 if rec:
                     k0, k1 = ("K", blk, s, 0), ("K", blk, s, 1)
@@ -113,8 +130,9 @@ def build(par, masked, dma):
                     rd(f"ds_read_b128 {slot_hi(sk)}, {ka(s, 1)} offset:@K+{blk * 32 * ROWB}", k1, g, fk)
                     c = "0" if s == 0 else sset(par, blk)
                     mfma[g] = (f"{MFMA} {sset(par, blk)}, {slot(sk)}, {qf(s)}, {c}", [k0, k1])
-        for dt in range(DT):
-            g = gP + dt
+
+    def alloc_p(rec, dt, g):
+        if True:
             sv, fv = take(g)
             if rec:
                 k0, k1 = ("VT", dt, 0), ("VT", dt, 1)
@@ -141,7 +159,7 @@ def build(par, masked, dma):
     k = 0
     for blk in (0, 1):
         for w in range(4):
-            rel, dl = max(0, k - 1), min(NS - 1, k + 1)
+            rel, dl = max(0, k - WIN), min(NS - 1, k + WIN)
             k += 1
             done = []
             for e, r in enumerate((4 * w, 4 * w + 1, 4 * w + 2, 4 * w + 3)):
@@ -156,20 +174,24 @@ def build(par, masked, dma):
     # ---- lane maxima of the keys j behind their A chains (masked variant: dead keys to -inf first), then the compare
     last = []
     prev = None
-    for blk in (0, 1):
-        rel = min(KS * blk + KS - 1 + 2, NS - 2)          # two later MFMAs have issued: the chain's last product has left the pipe
+    for blk in (() if nomax else (0, 1)):
+        rel = min(gA(blk, KS - 1) + 2, NS - 1)          # two later MFMAs have issued: the chain's last product has left the pipe
         masks = {}
         if masked:
             for r in range(16):
                 masks[r] = valu(f"v_cmp_gt_i32 vcc, %[hi], {32 * blk + r}\n\tv_cndmask_b32 {sreg(par, blk, r)}, %[ninf], {sreg(par, blk, r)}, vcc",
-                                "cmp", rel, NS - 2)
+                                "cmp", rel, NS - 1)
         for i in range(8):
             a, b = sreg(par, blk, 2 * i), sreg(par, blk, 2 * i + 1)
             text = f"v_max_f32 {RM}, {a}, {b}" if (blk == 0 and i == 0) else f"v_max3_f32 {RM}, {RM}, {a}, {b}"
             dep = ([prev] if prev else []) + ([masks[2 * i], masks[2 * i + 1]] if masked else [])
             prev = valu(text, "valu", rel, NS - 1, after=dep)
-    last.append(prev)
-    valu(f"v_cmp_gt_f32 vcc, {RM}, {TH}\n\ts_or_b32 %[need], vcc_lo, vcc_hi", "cmp", NS - 1, NS - 1, after=last)
+    if nomax:
+        # the caller has shown that no score of these keys can pass its row's threshold (fa2_fwd_fp8.hip: |q| |k| bound)
+        valu("s_mov_b32 %[need], 0", "valu", NS - 1, NS - 1)
+    else:
+        last.append(prev)
+        valu(f"v_cmp_gt_f32 vcc, {RM}, {TH}\n\ts_or_b32 %[need], vcc_lo, vcc_hi", "cmp", NS - 1, NS - 1, after=last)
 
     # ---- LDS-DMA of tile t + 2 (second halves only): two K pieces (rows 8 w .. and 64 + 8 w ..) and two V^T pieces (d rows
     #      16 w .. of the two key halves) per wave; LDS piece p of a tensor's tile lies 1 KiB x p into it
@@ -184,8 +206,8 @@ def build(par, masked, dma):
     return mfma, tasks
 
 
-def render(par, masked, dma, budget):
-    mfma, tasks = build(par, masked, dma)
+def render(par, masked, dma, budget, nomax=False):
+    mfma, tasks = build(par, masked, dma, nomax)
     per_gap, load = base.place(tasks, NS, budget)
     lines, pro = base.render_lines(mfma, per_gap, NS)
     return lines, pro, load
@@ -221,25 +243,28 @@ def main():
                                                   "fa2_fwd_fp8_body.inc"))
     args = ap.parse_args()
     chunks = ["// GENERATED by tools/gen_fwd_fp8_body.py -- do not edit.  Main-loop bodies of fa2_fwd_fp8_kernel (two waves per SIMD):\n"
-              "// FA2_F8_BODY_B<ring buffer>_K<half of the tile>_M<masked> and the prologue FA2_F8_PRO (the early reads of the very\n"
+              "// FA2_F8_BODY_B<ring buffer>_K<half of the tile>_<M0 plain | M1 masked | X no maxima> and the prologue FA2_F8_PRO (the early reads of the very\n"
               "// first body).  Register map, LDS map and schedule: the generator.\n",
               f"#define FA2_F8_V0 {V0}\n#define FA2_F8_SET0 {SET[0]}\n#define FA2_F8_SET1 {SET[1]}\n#define FA2_F8_PF0 {PF[0]}\n"
               f"#define FA2_F8_KA {KA}\n#define FA2_F8_VA {VA}\n#define FA2_F8_STATE {STATE}\n#define FA2_F8_VEND {VEND}\n"
               f"#define FA2_F8_A_QF {A_QF}\n#define FA2_F8_KV {KV}\n#define FA2_F8_NBUF {NBUF}\n"]
     pros = set()
-    for masked in (0, 1):
+    # variants: M0 plain, M1 masked (sequence tail, causal diagonal), X = plain without the lane maxima and the compare (the
+    # kernel runs it for keys whose scores it has bounded below every row's threshold: |q| |k| <= m + 6)
+    for tag, masked, nomax in (("M0", False, False), ("M1", True, False), ("X", False, True)):
         for kb in range(NH):
             par = kb & 1
             dma = kb == NH - 1
-            lines, pro, load = render(par, bool(masked), dma, BUDGET + (64 if masked else 0) + (8 if dma else 0))
+            nm = nomax or (os.environ.get("FA2_GEN_F8_NOMAX_ALL") == "1" and not masked)
+            lines, pro, load = render(par, masked, dma, BUDGET + ((64 if ORDER == 0 else 160) if masked else 0) + (8 if dma else 0), nomax=nm)
             pros.add(tuple(pro))
             if args.check:
-                print(f"kb={kb} masked={masked} dma={int(dma)}: {len(lines)} lines, {sum('v_mfma' in x for x in lines)} MFMAs, {len(pro)} early, "
+                print(f"kb={kb} {tag} dma={int(dma)}: {len(lines)} lines, {sum('v_mfma' in x for x in lines)} MFMAs, {len(pro)} early, "
                       f"max gap load {max(load)}, mean {sum(load) / len(load):.1f}")
                 print("   load:", " ".join(str(x) for x in load))
             for buf in range(NBUF):
                 body = resolve(lines, buf, kb, dma)
-                chunks.append(f"#define FA2_F8_BODY_B{buf}_K{kb}_M{masked} \\\n" + base.c_string(body) + "\n")
+                chunks.append(f"#define FA2_F8_BODY_B{buf}_K{kb}_{tag} \\\n" + base.c_string(body) + "\n")
     assert len(pros) == 1, "every body must leave the same reads in flight for the next one"
     p = resolve(list(pros.pop()), NBUF - 1, NH - 1, False)       # 'next' of the last half of buffer 3 = (buffer 0, half 0)
     p.append("s_waitcnt lgkmcnt(0)")

@@ -1,6 +1,10 @@
+"""Dev aid: the fp8 forward timed as bench.py times its side figure (50 ramp launches, median of 3 x 20), for A/B runs of
+library variants on ONE device: FA2_LIB_PATH=var/f8_<name>.so python tools/gpu_ab_fp8.py [quick]"""
 import sys, os, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cuda_flashattention_amd as fa
+
+
 def med(fn):
     for _ in range(50): fn()
     torch.cuda.synchronize()
@@ -12,9 +16,15 @@ def med(fn):
         e1.record(); torch.cuda.synchronize()
         v.append(e0.elapsed_time(e1) / 20)
     return sorted(v)[1]
-for (B, H, N, d, causal) in ((1, 16, 32768, 128, True), (1, 16, 32768, 128, False), (4, 16, 8192, 128, False), (4,16,4096,128,True)):
+
+
+quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
+cfgs = ((1, 16, 32768, 128, True), (1, 16, 32768, 128, False), (4, 16, 8192, 128, False), (4, 16, 4096, 128, True))
+out = []
+for (B, H, N, d, causal) in cfgs[:2] if quick else cfgs:
     Q, K, V = ((torch.rand(B, H, N, d, device="cuda") - 0.5).to(torch.float8_e4m3fn) for _ in range(3))
     O = torch.empty(B, H, N, d, dtype=torch.bfloat16, device="cuda"); L = torch.empty(B, H, N, device="cuda")
     ms = med(lambda: fa.flash_attention_2_forward(Q, K, V, None, causal=causal, O=O, L=L))
     fl = 4.0 * B * H * N * N * d * (0.5 if causal else 1.0)
-    print(f"{os.environ.get('FA2_LIB_PATH','new')}: fp8 fwd ({B},{H},{N},{d}) causal={causal}: {ms:.4f} ms  {fl / ms / 1e9:.0f} TFLOP/s", flush=True)
+    out.append(f"N={N}{'c' if causal else ' '} {ms:.4f} ms {fl / ms / 1e9:.0f} TF")
+print(f"{os.environ.get('FA2_LIB_PATH', 'product'):24s} " + " | ".join(out), flush=True)
