@@ -84,6 +84,9 @@ DQTILE = f"v[{DQT}:{DQT + 15}]"
 # packed multiplies (v_pk_mul_f32 for the two scalings of a register pair): MEASURED SLOWER -- 971K instead of 882K cycles per
 # unit at (4,16,8192,128); a v_pk_mul_f32 costs the issue port about as much as four plain multiplies.  Kept as a switch.
 PK = os.environ.get("FA2_GEN_PK", "0") == "1"
+# K image pre-scaled by scale * log2 e (fa2_bwd_fused.hip scales it once per unit): S' arrives in the exp2 domain and the
+# multiply in front of each exponential goes away (32 of a body's ~135 VALU instructions)
+KSCALED = os.environ.get("FA2_GEN_KSCALED", "0") == "1"
 
 
 def build(chain=False, masked=False):
@@ -202,8 +205,8 @@ def build(chain=False, masked=False):
                 # loop is bound by what one wave can ISSUE, and a packed fp32 multiply issues like a plain one
                 m2 = valu(f"v_pk_mul_f32 v[{a0}:{a0 + 1}], v[{a0}:{a0 + 1}], %[c2p]", "valu", rel_exp, use_pf - 5) if PK else None
                 for r in (r0, r0 + 1):
-                    m = m2 or valu(f"v_mul_f32 {sreg(kb, r)}, %[c2], {sreg(kb, r)}", "valu", rel_exp, use_pf - 5)
-                    e = valu(f"v_exp_f32 {sreg(kb, r)}, {sreg(kb, r)}", "exp", rel_exp, use_pf - 4, after=[m])
+                    m = None if KSCALED else (m2 or valu(f"v_mul_f32 {sreg(kb, r)}, %[c2], {sreg(kb, r)}", "valu", rel_exp, use_pf - 5))
+                    e = valu(f"v_exp_f32 {sreg(kb, r)}, {sreg(kb, r)}", "exp", rel_exp, use_pf - 4, after=[m] if m else None)
                     if masked:
                         # causal: P = 0 where the lane's key lies above the row.  Row of register r within the sub-tile =
                         # (r & 3) + 8 (r >> 2) + 4 h; %[lo<kb>] (per lane) = key - 32 tile - 4 h: keep iff row >= key
