@@ -39,7 +39,7 @@ SUSTAINED_MFMA_TFLOPS = 1840.0
 PMC_TRAFFIC_FILE = os.path.join("profiles", "pmc_traffic.json")
 PEAK_FP8_TFLOPS = 5033.2    # dense fp8 MFMA (v_mfma_f32_32x32x64_f8f6f4): twice the bf16 rate
 # PMC evidence for the two side configurations (MFMA-busy, clock, VALU / LDS / wait split, FETCH / WRITE): see profiles/README.md
-SIDE_PMC_FILE = os.path.join("profiles", "r3_b_side_pmc_summary.txt")
+SIDE_PMC_FILE = os.path.join("profiles", "r3_e_side_pmc_summary.txt")
 B, H, N, D = 4, 16, 8192, 128
 
 
@@ -268,9 +268,9 @@ def main():
                 return {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1), "timing": "median of 3 x 20 launches after 50 warm-up launches",
                         "roofline": {"bound": "mfma", "achieved": round(fl / ms / 1e9, 1), "peak": peak, "unit": "TFLOP/s",
                                      "frac": round(fl / ms / 1e9 / peak, 4), "counters": SIDE_PMC_FILE,
-                                     "limiting_unit": "VALU issue under the chip's power limit: 4 (bf16) / 4.5 (fp8) VALU instructions per "
+                                     "limiting_unit": "VALU issue under the chip's power limit: 4 (bf16) / 3.5 - 4 (fp8) VALU instructions per "
                                                       "S element against half (d = 64) or a quarter (fp8) of the MFMA cycles of bf16 d = 128; "
-                                                      "44.6 % / 42.5 % MFMA-busy in the PMC passes (DESIGN.md section 3)"}}
+                                                      "45.1 % / 53.0 % MFMA-busy at 2.04 GHz in the PMC passes (DESIGN.md section 3)"}}
             extra["fwd_bf16_cfg2_(4,16,4096,64)"] = fwd_only(4, 16, 4096, 64, torch.bfloat16, False)
             extra["fwd_fp8_e4m3_causal_cfg5_(1,16,32768,128)"] = fwd_only(1, 16, 32768, 128, torch.float8_e4m3fn, True)
             # the headline shape with a causal mask (past the reference, which has none): forward + backward, 7 B H N^2 d flops
