@@ -20,6 +20,16 @@
 // an SGPR; the rare update is compiler code between two bodies.  With the pipeline two blocks deep, at that point O^T holds
 // the products through block j-2, the row sums through block j-1, and P(j-1) is packed and waiting: the sums are rescaled
 // at once, O^T one body later (after P(j-1), formed at the old reference, has been added to it).
+//
+// Lane maxima in the first tile only (round 3, second half).  The running maximum of the online softmax does two jobs: it
+// gives the exponentials a reference, and it keeps them in range.  In fp32 sums and bf16 P -- whose relative precision does
+// not depend on magnitude -- a reference that lags the true maximum by tens of units costs nothing: O / l comes out the same
+// to rounding.  So a workgroup takes the lane maxima during its first tile (which establishes the reference, with the
+// lazy update above) and then runs the X variant of the bodies -- no v_max3_f32 (16 of a body-pair's ~146
+// VALU instructions), no compare.  What the maxima guarded against, a score more than ~60 above the reference, shows in the row
+// sums: if any row of the workgroup ends with l not below 2^80 (or not finite), the workgroup runs its row block again with
+// the maxima in every body (`safe`), as before.  Tail, diagonal and drain bodies keep their maxima either way.
+// Measured same-box: (4,16,4096,64) 945 -> ~990 TFLOP/s, (4,16,8192,128) 1.692 -> ~1.65 ms.
 #include <type_traits>
 
 #include "fa2_common.h"
@@ -32,6 +42,8 @@ namespace fa2 {
 constexpr int kF1Rows = 256;                 // query rows per workgroup (4 waves x 64 or 8 waves x 32)
 constexpr int kF1Bufs = 4;                  // LDS ring depth (tools/gen_fwd_body.py: NBUF)
 constexpr float kF1RescaleThr = 6.0f;       // natural-log units of the scaled score
+constexpr float kF1SumLimit = 1.2089258e24f; // 2^80: a row sum at or above it sends the workgroup through its row block again, with maxima
+enum { F1_PLAIN = 0, F1_MASKED = 1, F1_NOMAX = 2 };
 
 typedef __attribute__((address_space(3))) void* f1_lptr_t;
 
@@ -123,23 +135,25 @@ struct F1Dma {
     uint32_t mw, dvo, kso;
 };
 
-// One body.  KB < NH - 1: plain; KB == NH - 1: starts with the tile barrier and issues the DMA of tile t + 2.
-template <int D, int QBS, int BUF, int KB, bool MASKED>
+// One body.  KB < NH - 1: plain; KB == NH - 1: starts with the tile barrier and issues the DMA of tile t + 2.  MODE: with
+// maxima (F1_PLAIN), with maxima and the mask (F1_MASKED), without maxima (F1_NOMAX: `need` comes back 0).
+template <int D, int QBS, int BUF, int KB, int MODE>
 __device__ __forceinline__ void f1_body(float c2, int& need, const int (&hi)[2], const F1Dma& dma)
 {
-#define FA2_F1_CASE(TAG, DD, QQ, B, K, M)                                                                                          \
-    if constexpr (D == DD && QBS == QQ && BUF == B && KB == K && MASKED == bool(M))                                                  \
-        FA2_F1_ASM(QQ, FA2_FWD_BODY_##TAG##_B##B##_K##K##_M##M, [need] "=&s"(need),                                                    \
+#define FA2_F1_CASE(TAG, DD, QQ, B, K, MV, M)                                                                                      \
+    if constexpr (D == DD && QBS == QQ && BUF == B && KB == K && MODE == MV)                                                         \
+        FA2_F1_ASM(QQ, FA2_FWD_BODY_##TAG##_B##B##_K##K##_##M, [need] "=&s"(need),                                                     \
                    [c2] "s"(c2) FA2_F1_COMMA [hi0] "v"(hi[0]) FA2_F1_COMMA [hi1] "v"(hi[1]) FA2_F1_COMMA [ninf] "v"(-INFINITY)           \
                        FA2_F1_COMMA [mw] "s"(dma.mw) FA2_F1_COMMA [dvo] "v"(dma.dvo) FA2_F1_COMMA [krs] "s"(dma.krs)                     \
                        FA2_F1_COMMA [vrs] "s"(dma.vrs) FA2_F1_COMMA [kso] "s"(dma.kso));
-#define FA2_F1_CASES_B(TAG, DD, QQ, K, M) \
-    FA2_F1_CASE(TAG, DD, QQ, 0, K, M) FA2_F1_CASE(TAG, DD, QQ, 1, K, M) FA2_F1_CASE(TAG, DD, QQ, 2, K, M) FA2_F1_CASE(TAG, DD, QQ, 3, K, M)
-    FA2_F1_CASES_B(D128Q2, 128, 2, 0, 0) FA2_F1_CASES_B(D128Q2, 128, 2, 1, 0) FA2_F1_CASES_B(D128Q2, 128, 2, 0, 1) FA2_F1_CASES_B(D128Q2, 128, 2, 1, 1)
-    FA2_F1_CASES_B(D64Q2, 64, 2, 0, 0) FA2_F1_CASES_B(D64Q2, 64, 2, 1, 0) FA2_F1_CASES_B(D64Q2, 64, 2, 2, 0) FA2_F1_CASES_B(D64Q2, 64, 2, 3, 0)
-    FA2_F1_CASES_B(D64Q2, 64, 2, 0, 1) FA2_F1_CASES_B(D64Q2, 64, 2, 1, 1) FA2_F1_CASES_B(D64Q2, 64, 2, 2, 1) FA2_F1_CASES_B(D64Q2, 64, 2, 3, 1)
-    FA2_F1_CASES_B(D64Q1, 64, 1, 0, 0) FA2_F1_CASES_B(D64Q1, 64, 1, 1, 0) FA2_F1_CASES_B(D64Q1, 64, 1, 2, 0) FA2_F1_CASES_B(D64Q1, 64, 1, 3, 0)
-    FA2_F1_CASES_B(D64Q1, 64, 1, 0, 1) FA2_F1_CASES_B(D64Q1, 64, 1, 1, 1) FA2_F1_CASES_B(D64Q1, 64, 1, 2, 1) FA2_F1_CASES_B(D64Q1, 64, 1, 3, 1)
+#define FA2_F1_CASES_B(TAG, DD, QQ, K, MV, M) \
+    FA2_F1_CASE(TAG, DD, QQ, 0, K, MV, M) FA2_F1_CASE(TAG, DD, QQ, 1, K, MV, M) FA2_F1_CASE(TAG, DD, QQ, 2, K, MV, M) FA2_F1_CASE(TAG, DD, QQ, 3, K, MV, M)
+#define FA2_F1_CASES_V(TAG, DD, QQ, K) \
+    FA2_F1_CASES_B(TAG, DD, QQ, K, F1_PLAIN, M0) FA2_F1_CASES_B(TAG, DD, QQ, K, F1_MASKED, M1) FA2_F1_CASES_B(TAG, DD, QQ, K, F1_NOMAX, X)
+    FA2_F1_CASES_V(D128Q2, 128, 2, 0) FA2_F1_CASES_V(D128Q2, 128, 2, 1)
+    FA2_F1_CASES_V(D64Q2, 64, 2, 0) FA2_F1_CASES_V(D64Q2, 64, 2, 1) FA2_F1_CASES_V(D64Q2, 64, 2, 2) FA2_F1_CASES_V(D64Q2, 64, 2, 3)
+    FA2_F1_CASES_V(D64Q1, 64, 1, 0) FA2_F1_CASES_V(D64Q1, 64, 1, 1) FA2_F1_CASES_V(D64Q1, 64, 1, 2) FA2_F1_CASES_V(D64Q1, 64, 1, 3)
+#undef FA2_F1_CASES_V
 #undef FA2_F1_CASES_B
 #undef FA2_F1_CASE
 }
@@ -234,9 +248,6 @@ __device__ __forceinline__ void fa2_fwd1_impl(const FwdArgs& p)
                                                      (t * KV + piece * RPI) * ROWB, 0, 0);
         }
     };
-    stage(0, 0);
-    stage(1, 1);
-    stage(0, 3);          // "the tile before the first": read by the first bodies' P stage (against P = 0): must be finite
 
     // ---- Q fragments -> AGPRs; lane holds Q[q][16 s + 8 h .. +7] of rows q0 + 32 qb + qi
     int qrow[QBS];
@@ -255,43 +266,50 @@ __device__ __forceinline__ void fa2_fwd1_impl(const FwdArgs& p)
     // for a new reference live in the registers the bodies name (ST ...) and are rewritten only by the rare update below.
     const float inv_scale = 1.0f / p.scale;
     float m_run[QBS], pend[QBS];
-#pragma unroll
-    for (int qb = 0; qb < QBS; ++qb) pend[qb] = 1.0f;
     bool have_pend = false;
-    if (STATE && p.resume) {
-        static_for<QBS>([&](auto QB) {
-            constexpr int qb = decltype(QB)::value;
-            const int qld = qrow[qb] < Nq ? qrow[qb] : Nq - 1;
-            const float* Oa = p.Oacc + ((size_t)head * qhs + qld) * D;
-            static_for<4 * DT>([&](auto G) {
-                constexpr int dt = decltype(G)::value / 4, g = decltype(G)::value % 4;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(Oa + 32 * dt + 8 * g + 4 * h);
-                static_for<4>([&](auto E) { f1_awrite<QBS, A_O + (qb * DT + dt) * 16 + 4 * g + decltype(E)::value>(v[decltype(E)::value]); });
+    // (re)starts a pass over the row block: the first tiles' DMA, O^T, the softmax state, the "blocks before the first"
+    auto init_pass = [&]() {
+        stage(0, 0);
+        stage(1, 1);
+        stage(0, 3);          // "the tile before the first": read by the first bodies' P stage (against P = 0): must be finite
+#pragma unroll
+        for (int qb = 0; qb < QBS; ++qb) pend[qb] = 1.0f;
+        have_pend = false;
+        if (STATE && p.resume) {
+            static_for<QBS>([&](auto QB) {
+                constexpr int qb = decltype(QB)::value;
+                const int qld = qrow[qb] < Nq ? qrow[qb] : Nq - 1;
+                const float* Oa = p.Oacc + ((size_t)head * qhs + qld) * D;
+                static_for<4 * DT>([&](auto G) {
+                    constexpr int dt = decltype(G)::value / 4, g = decltype(G)::value % 4;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(Oa + 32 * dt + 8 * g + 4 * h);
+                    static_for<4>([&](auto E) { f1_awrite<QBS, A_O + (qb * DT + dt) * 16 + 4 * g + decltype(E)::value>(v[decltype(E)::value]); });
+                });
+                m_run[qb] = p.M[(size_t)head * qhs + qld];
+                f1_vsetf<QBS, ST + 2 * qb>(h == 0 ? p.L[(size_t)head * qhs + qld] : 0.0f);
+                f1_vsetf<QBS, ST + 2 * qb + 1>(0.0f);
+                f1_vsetf<QBS, ST_MB + qb>(m_run[qb] == -INFINITY ? 0.0f : m_run[qb] * kLog2e);
+                f1_vsetf<QBS, ST_TH + qb>((m_run[qb] + kF1RescaleThr) * inv_scale);
             });
-            m_run[qb] = p.M[(size_t)head * qhs + qld];
-            f1_vsetf<QBS, ST + 2 * qb>(h == 0 ? p.L[(size_t)head * qhs + qld] : 0.0f);
-            f1_vsetf<QBS, ST + 2 * qb + 1>(0.0f);
-            f1_vsetf<QBS, ST_MB + qb>(m_run[qb] == -INFINITY ? 0.0f : m_run[qb] * kLog2e);
-            f1_vsetf<QBS, ST_TH + qb>((m_run[qb] + kF1RescaleThr) * inv_scale);
+        } else {
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            static_for<QBS * DT>([&](auto T) { f1_acc_zero<QBS, A_O + 16 * decltype(T)::value>(z); });
+            static_for<QBS>([&](auto QB) {
+                constexpr int qb = decltype(QB)::value;
+                m_run[qb] = -INFINITY;
+                f1_vsetf<QBS, ST + 2 * qb>(0.0f);
+                f1_vsetf<QBS, ST + 2 * qb + 1>(0.0f);
+                f1_vsetf<QBS, ST_MB + qb>(0.0f);
+                f1_vsetf<QBS, ST_TH + qb>(-INFINITY);
+            });
+        }
+        // S sets and packed P of "the blocks before the first": exp2(-huge) = 0 and P = 0, so the first two bodies add exactly zero
+        static_for<16 * QBS>([&](auto R) {
+            f1_vsetf<QBS, SET0 + decltype(R)::value>(-1.0e30f);
+            f1_vsetf<QBS, SET1 + decltype(R)::value>(-1.0e30f);
+            f1_vset<QBS, PF0 + decltype(R)::value>(0u);
         });
-    } else {
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        static_for<QBS * DT>([&](auto T) { f1_acc_zero<QBS, A_O + 16 * decltype(T)::value>(z); });
-        static_for<QBS>([&](auto QB) {
-            constexpr int qb = decltype(QB)::value;
-            m_run[qb] = -INFINITY;
-            f1_vsetf<QBS, ST + 2 * qb>(0.0f);
-            f1_vsetf<QBS, ST + 2 * qb + 1>(0.0f);
-            f1_vsetf<QBS, ST_MB + qb>(0.0f);
-            f1_vsetf<QBS, ST_TH + qb>(-INFINITY);
-        });
-    }
-    // S sets and packed P of "the blocks before the first": exp2(-huge) = 0 and P = 0, so the first two bodies add exactly zero
-    static_for<16 * QBS>([&](auto R) {
-        f1_vsetf<QBS, SET0 + decltype(R)::value>(-1.0e30f);
-        f1_vsetf<QBS, SET1 + decltype(R)::value>(-1.0e30f);
-        f1_vset<QBS, PF0 + decltype(R)::value>(0u);
-    });
+    };
 
     // ---- loop-invariant LDS addresses into the registers the bodies name
     const uint32_t lbase = (uint32_t)(uintptr_t)smem;
@@ -313,15 +331,12 @@ __device__ __forceinline__ void fa2_fwd1_impl(const FwdArgs& p)
     dma.dvo = (uint32_t)doff;
     dma.kso = 0;
 
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                         // tiles 0 and 1 have landed
 #ifndef FA2_F1_NO_SETPRIO
     // two waves per SIMD: the later-dispatched half of the workgroup loses every issue arbitration to the older half
     // (priority, then age); one static priority bump for that half evens them out (MI355X_MICROARCH.md, 'Two waves per SIMD')
     if constexpr (QBS == 1)
         if (wave >= kF1Waves / 2) __builtin_amdgcn_s_setprio(1);
 #endif
-    f1_prologue<D, QBS>();
 
     // ---- the rare path between two bodies: first the O^T rescale left over from the previous update, then a new reference
     auto update = [&](int need) {
@@ -359,11 +374,13 @@ __device__ __forceinline__ void fa2_fwd1_impl(const FwdArgs& p)
         }
     };
 
-    // GENERAL = false: every body of the tile is known to exist and to be unmasked for this wave (no per-body decisions: the
-    // only code between two bodies is the test of the flag the body returns); GENERAL = true: tail, diagonal and drain tiles.
-    auto run_tile = [&](auto B_, auto GENERAL_, int t) {
+    // FLAVOUR 0 / 2: every body of the tile is known to exist and to be unmasked for this wave (no per-body decisions: the
+    // only code between two bodies is the test of the flag the body returns), with (0) or without (2) the lane maxima;
+    // FLAVOUR 1 = GENERAL: tail, diagonal and drain tiles.
+    auto run_tile = [&](auto B_, auto FLAVOUR_, int t) {
         constexpr int B = decltype(B_)::value;
-        constexpr bool GENERAL = decltype(GENERAL_)::value;
+        constexpr bool GENERAL = decltype(FLAVOUR_)::value == 1;
+        constexpr int FAST = decltype(FLAVOUR_)::value == 2 ? F1_NOMAX : F1_PLAIN;
         dma.kso = (uint32_t)(((t + 2) * KV + wave * RPI) * ROWB);
         static_for<NH>([&](auto KB_) {
             constexpr int kb = decltype(KB_)::value;
@@ -378,14 +395,14 @@ __device__ __forceinline__ void fa2_fwd1_impl(const FwdArgs& p)
                     int hi[2] = {0, 0};
 #pragma unroll
                     for (int qb = 0; qb < QBS; ++qb) hi[qb] = (CAUSAL ? min(Nk, qrow[qb] + p.causal_shift + 1) : Nk) - key0 - 4 * h;
-                    f1_body<D, QBS, B, kb, true>(c2, need, hi, dma);
+                    f1_body<D, QBS, B, kb, F1_MASKED>(c2, need, hi, dma);
                 } else {
                     const int hi[2] = {0, 0};
-                    f1_body<D, QBS, B, kb, false>(c2, need, hi, dma);
+                    f1_body<D, QBS, B, kb, F1_PLAIN>(c2, need, hi, dma);
                 }
             } else {
                 const int hi[2] = {0, 0};
-                f1_body<D, QBS, B, kb, false>(c2, need, hi, dma);
+                f1_body<D, QBS, B, kb, FAST>(c2, need, hi, dma);
             }
             // (both are SGPR values already; the readfirstlane tells hipcc that the branch is uniform)
             if (__builtin_amdgcn_readfirstlane(need | (int)have_pend)) update(need);
@@ -396,24 +413,56 @@ __device__ __forceinline__ void fa2_fwd1_impl(const FwdArgs& p)
     int nfull = Nk / KV;
     if (CAUSAL) nfull = min(nfull, max(0, (q0 + p.causal_shift + 1) / KV));
     nfull = min(nfull, J / NH) & ~3;                       // whole rounds of the ring of four
-    int t = 0;
-    for (; t < nfull; t += 4) {
-        run_tile(std::integral_constant<int, 0>{}, std::false_type{}, t);
-        run_tile(std::integral_constant<int, 1>{}, std::false_type{}, t + 1);
-        run_tile(std::integral_constant<int, 2>{}, std::false_type{}, t + 2);
-        run_tile(std::integral_constant<int, 3>{}, std::false_type{}, t + 3);
+    int nfull_wg = Nk / KV;
+    if (CAUSAL) nfull_wg = min(nfull_wg, max(0, (rb * kF1Rows + (kF1Waves - 1) * WROWS + p.causal_shift + 1) / KV));
+    nfull_wg = min(nfull_wg, J / NH) & ~3;
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    // Pass 0: lane maxima in the first tile only (see the header).  Pass 1 (`safe`), entered only when a row
+    // sum of the workgroup left the range pass 0 vouches for: maxima in every body.
+    int* const redo_flag = reinterpret_cast<int*>(smem + 2 * KRING);
+    bool safe = false;
+    for (;;) {
+        init_pass();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                         // tiles 0 and 1 have landed
+        f1_prologue<D, QBS>();
+        int t = 0;
+        for (; t < nfull; t += 4) {
+            if (safe) {
+                run_tile(I0{}, I0{}, t); run_tile(I1{}, I0{}, t + 1); run_tile(I2{}, I0{}, t + 2); run_tile(I3{}, I0{}, t + 3);
+            } else if (t == 0) {             // the first tile establishes the reference
+                run_tile(I0{}, I0{}, t); run_tile(I1{}, I2{}, t + 1); run_tile(I2{}, I2{}, t + 2); run_tile(I3{}, I2{}, t + 3);
+            } else {
+                run_tile(I0{}, I2{}, t); run_tile(I1{}, I2{}, t + 1); run_tile(I2{}, I2{}, t + 2); run_tile(I3{}, I2{}, t + 3);
+            }
+        }
+        for (; t < ntl; t += 4) {
+            run_tile(I0{}, I1{}, t);
+            if (t + 1 >= ntl) break;
+            run_tile(I1{}, I1{}, t + 1);
+            if (t + 2 >= ntl) break;
+            run_tile(I2{}, I1{}, t + 2);
+            if (t + 3 >= ntl) break;
+            run_tile(I3{}, I1{}, t + 3);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // the last bodies' look-ahead DMA and reads
+        // Did any row of the WORKGROUP leave the range the X rounds vouch for?  (Every decision here is workgroup-uniform:
+        // the restart goes through the tile barriers again.  nfull_wg: the workgroup's last wave has the most full rounds.)
+        if (safe || nfull_wg == 0) break;
+        bool bad = false;
+        static_for<QBS>([&](auto QB) {
+            constexpr int qb = decltype(QB)::value;
+            bad = bad || !(half_sum(f1_vget<ST + 2 * qb>() + f1_vget<ST + 2 * qb + 1>()) < kF1SumLimit);      // also true for NaN
+        });
+        if (tid == 0) *redo_flag = 0;
+        __syncthreads();
+        if (__any(bad) && lane == 0) *redo_flag = 1;
+        __syncthreads();
+        if (*redo_flag == 0) break;
+        asm volatile("; fa2-cold: a row sum left the range of the rounds without maxima: the row block again, with maxima");
+        safe = true;
     }
-    for (; t < ntl; t += 4) {
-        run_tile(std::integral_constant<int, 0>{}, std::true_type{}, t);
-        if (t + 1 >= ntl) break;
-        run_tile(std::integral_constant<int, 1>{}, std::true_type{}, t + 1);
-        if (t + 2 >= ntl) break;
-        run_tile(std::integral_constant<int, 2>{}, std::true_type{}, t + 2);
-        if (t + 3 >= ntl) break;
-        run_tile(std::integral_constant<int, 3>{}, std::true_type{}, t + 3);
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // the last bodies' look-ahead DMA and reads
-
     // ---- epilogue
     mfma_acc_settle();
     const bool fin = !STATE || p.finalize;
@@ -476,7 +525,7 @@ __global__ void __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(40))) f
 template <int D, bool CAUSAL, bool STATE>
 static hipError_t launch_one1(const FwdArgs& a, hipStream_t stream)
 {
-    constexpr int lds = 2 * kF1Bufs * 16384;
+    constexpr int lds = 2 * kF1Bufs * 16384 + 16;          // the two rings + the workgroup's restart flag
     const int nrb = (a.Nq + kF1Rows - 1) / kF1Rows;
     static bool attr_set[64] = {};
     if constexpr (D == 64 && FA2_FWD64_QBS == 1) {

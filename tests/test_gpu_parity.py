@@ -116,6 +116,32 @@ def test_fwd_rescale_branch_forced():
     assert np.isfinite(f32(O)).all()
 
 
+@pytest.mark.parametrize("d,causal", [(128, False), (64, False), (128, True)])
+def test_fwd_rounds_without_maxima_late_spikes_and_the_restart(d, causal):
+    """After its first tile the bf16 forward takes no lane maxima (fa2_fwd1_bf16.hip): the reference
+    stays where the first round left it, and a workgroup whose row sums leave the vouched range runs its row block again with
+    maxima.  Three heads of one launch: ordinary data (the rounds without maxima); a late key 28 natural units above its rows'
+    reference (no rescale any more: p ~ e^28 against the old reference, O / l must come out the same); and a late key ~130
+    units above (exp overflows: the restart).  All against the oracle, with the forced-rescale case's gates."""
+    fa, oracle = _fa(), _oracle()
+    B, H, N = 1, 3, 4096
+    Q, K, V = make(B, H, N, d, 31), make(B, H, N, d, 32), make(B, H, N, d, 33)
+    Qf, K = Q.float(), K.float()
+    q1, q2 = Qf[0, 1, 3000], Qf[0, 2, 3900]
+    s = 1.0 / d ** 0.5
+    K[0, 1, 2500] = q1 * (28.0 / (s * float(q1 @ q1)))          # score 28 / scale with row 3000 (visible under the mask: 2500 <= 3000)
+    K[0, 2, 3000] = q2 * (130.0 / (s * float(q2 @ q2)))         # score 130 / scale with row 3900
+    K = K.bfloat16()
+    O, L = fa.flash_attention_2_forward(Q.cuda(), K.cuda(), V.cuda(), s, causal=causal)
+    torch.cuda.synchronize()
+    Or, Lr = oracle.attention_forward(f32(Q), f32(K), f32(V), s, causal=causal)
+    assert np.isfinite(f32(O)).all() and np.isfinite(L.cpu().numpy()).all()
+    assert Lr[0, 1, 3000] > 25.0 and Lr[0, 2, 3900] > 120.0        # the spikes are what the test says they are
+    assert rel(f32(O), Or) <= BF16_REL
+    assert np.abs(L.cpu().numpy() - Lr).max() <= 1e-3
+    assert np.abs(L.cpu().numpy()[0, 0] - Lr[0, 0]).max() <= 1e-4
+
+
 # ----------------------------------------------------------------------------- bf16 backward
 @pytest.mark.parametrize("B,H,N,d,causal", [
     (1, 2, 128, 64, False),

@@ -130,7 +130,7 @@ def test_generated_forward_kernel(asm):
     """What fa2_forward runs for bf16 (csrc/fa2_fwd1_bf16.hip, bodies from tools/gen_fwd_body.py), in its two shapes:
     fa2_fwd1_bf16_kernel -- one wave per SIMD, 64 rows per wave, amdgpu_num_vgpr(64), 512 registers -- and
     fa2_fwd1x2_bf16_kernel -- two waves per SIMD, 32 rows per wave, amdgpu_num_vgpr(40), 128 + 128 registers (d = 64).
-    Per ring buffer and key block of a tile there is a plain and a masked body with QBS (KS + 2 DT) MFMAs; the bodies of a
+    Per ring buffer and key block of a tile there is a plain, a masked and a no-maxima body with QBS (KS + 2 DT) MFMAs; the bodies of a
     tile's last key block open with vmcnt(0) + s_barrier and carry the LDS-DMA pieces of the tile two ahead (32 per
     workgroup and tile); nothing outside the asm regions names a body register."""
     ks = {n: k for n, k in _kernels(asm["fa2_fwd1_bf16"]).items() if "fa2_fwd1" in n and "bf16_kernel" in n}
@@ -150,10 +150,11 @@ def test_generated_forward_kernel(asm):
         assert k["meta"]["scratch"] == 0 and k["meta"]["vgpr_spill"] == 0, (name, k["meta"])
         assert k["meta"]["total"] == (512 if qbs == 2 else 256), (name, k["meta"])
         bodies = [b for b in blocks if sum("v_mfma_f32_32x32x16_bf16" in s for s in b) == per_body and len(b) > 4 * per_body]
-        # the loop over whole unmasked rounds holds 4 nh plain bodies; the general loop 4 nh plain + 4 nh masked
-        assert len(bodies) == 12 * nh, (name, len(bodies))
+        # the loop over whole unmasked rounds holds three rounds of 4 tiles: with maxima (a `safe` pass), first tile with and
+        # the other three without (the first round), all without; the general loop 4 nh plain + 4 nh masked bodies
+        assert len(bodies) == 20 * nh, (name, len(bodies))
         with_barrier = [b for b in bodies if any(s.startswith("s_barrier") for s in b)]
-        assert len(with_barrier) == 12            # one per tile
+        assert len(with_barrier) == 20            # one per tile
         for b in with_barrier:
             assert b[0].startswith("s_waitcnt vmcnt(0)") and b[1].startswith("s_barrier")
             assert sum(s.startswith("buffer_load_dwordx4") and s.endswith(" lds") for s in b) == 32 // (8 // qbs)
@@ -161,6 +162,7 @@ def test_generated_forward_kernel(asm):
             if b not in with_barrier:
                 assert not any("buffer_load" in s for s in b)
         assert sum(any(s.startswith("v_cndmask_b32") for s in b) for b in bodies) == 4 * nh      # the masked variants
+        assert sum(not any(s.startswith("v_max3_f32") for s in b) for b in bodies) == 7 * nh      # the variants without maxima
 
 
 def test_fused_backward_kernel(asm):
@@ -294,7 +296,7 @@ def test_generated_bodies_pass_the_static_checker(inc):
     spec.loader.exec_module(cb)
     text = open(os.path.join(CSRC, inc)).read()
     names = re.findall(r"#define (FA2_\w+_[CM]?BODY_\w+) ", text)
-    assert len(names) in (12, 16, 18, 24, 80)
+    assert len(names) in (12, 16, 18, 24, 120)
     for n in names:
         assert cb.check(cb.body(text, n), n) == []
 

@@ -96,7 +96,7 @@ class Regs:
     def o(self, qb, dt): b = self.A_O + 16 * (qb * self.DT + dt); return f"a[{b}:{b + 15}]"
 
 
-def build(D, QBS, par, masked, dma):
+def build(D, QBS, par, masked, dma, nomax=False):
     """One body for a key block of parity `par` (S set / PF set selection).  Gap units 0 .. NS-1; tasks with a negative
     release belong to the tail of the previous body (they are emitted there with the NEXT body's bases: '@N')."""
     R = Regs(D, QBS)
@@ -181,7 +181,10 @@ def build(D, QBS, par, masked, dma):
 
     # ---- lane maxima of block j behind its A chains (masked variant: dead keys to -inf first), then the compare
     last = []
-    for qb in QB:
+    # X variant: no lane maxima, no compare -- the kernel runs it where it does not move the reference (fa2_fwd1_bf16.hip);
+    # FA2_GEN_FWD_NOMAX_ALL=1 (experiment): every plain body, the upper bound of what the X rounds can gain
+    nomax = nomax or (os.environ.get("FA2_GEN_FWD_NOMAX_ALL") == "1" and not masked)
+    for qb in (() if nomax else QB):
         rel = min(QBS * (KS - 1) + qb + 3, NS - 3)          # the chain's last product has left the matrix pipe
         prev = None
         masks = {}
@@ -196,7 +199,9 @@ def build(D, QBS, par, masked, dma):
             dep = ([prev] if prev else []) + ([masks[2 * i], masks[2 * i + 1]] if masked else [])
             prev = valu(text, "valu", rel, NS - 2, after=dep)
         last.append(prev)
-    if QBS == 2:
+    if nomax:
+        valu("s_mov_b32 %[need], 0", "valu", NS - 2, NS - 1)
+    elif QBS == 2:
         valu(f"v_cmp_gt_f32 vcc, {R.rm(0)}, {R.th(0)}\n\tv_cmp_gt_f32 s[10:11], {R.rm(1)}, {R.th(1)}\n\ts_or_b64 vcc, vcc, s[10:11]\n\t"
              "s_or_b32 %[need], vcc_lo, vcc_hi", "cmp", NS - 2, NS - 1, after=last)
     else:
@@ -220,8 +225,8 @@ def build(D, QBS, par, masked, dma):
     return R, mfma, tasks, NS
 
 
-def render(D, QBS, par, masked, dma, budget):
-    R, mfma, tasks, NS = build(D, QBS, par, masked, dma)
+def render(D, QBS, par, masked, dma, budget, nomax=False):
+    R, mfma, tasks, NS = build(D, QBS, par, masked, dma, nomax)
     per_gap, load = base.place(tasks, NS, budget)
     lines, pro = base.render_lines(mfma, per_gap, NS)
     return R, lines, pro, load, NS
@@ -261,7 +266,7 @@ def main():
                                                   "fa2_fwd_body.inc"))
     args = ap.parse_args()
     chunks = ["// GENERATED by tools/gen_fwd_body.py -- do not edit.  Main-loop bodies of fa2_fwd1_bf16_kernel (one wave per SIMD):\n"
-              "// FA2_FWD_BODY_D<d>_B<ring buffer>_K<key block of the tile>_M<masked> and the prologue FA2_FWD_PRO_D<d> (the early reads\n"
+              "// FA2_FWD_BODY_D<d>Q<row blocks>_B<ring buffer>_K<key block of the tile>_<M0 plain | M1 masked | X no maxima> and the prologue FA2_FWD_PRO_D<d> (the early reads\n"
               "// of the very first body).  Register map, LDS map and schedule: the generator.\n"]
     for D, QBS in CONFIGS:
         R0 = Regs(D, QBS)
@@ -272,19 +277,19 @@ def main():
                       f"#define FA2_FWD_{tag}_KV {R0.KV}\n#define FA2_FWD_{tag}_STATE {R0.STATE}\n#define FA2_FWD_{tag}_V0 {R0.V0}\n"
                       f"#define FA2_FWD_{tag}_A_QF {R0.A_QF}\n")
         pros = set()
-        for masked in (0, 1):
+        for vtag, masked, nomax in (("M0", False, False), ("M1", True, False), ("X", False, True)):
             for kb in range(R0.NH):
                 par = kb & 1
                 dma = kb == R0.NH - 1
-                R, lines, pro, load, NS = render(D, QBS, par, bool(masked), dma, budget + (12 if masked else 0) + (4 if dma else 0))
+                R, lines, pro, load, NS = render(D, QBS, par, masked, dma, budget + (12 if masked else 0) + (4 if dma else 0), nomax)
                 pros.add(tuple(pro))
                 if args.check:
-                    print(f"{tag} kb={kb} masked={masked} dma={int(dma)}: {len(lines)} lines, {sum('v_mfma' in l for l in lines)} MFMAs, "
+                    print(f"{tag} kb={kb} {vtag} dma={int(dma)}: {len(lines)} lines, {sum('v_mfma' in l for l in lines)} MFMAs, "
                           f"{len(pro)} early, max gap load {max(load)}, mean {sum(load) / len(load):.1f}")
                     print("   load:", " ".join(str(l) for l in load))
                 for buf in range(NBUF):
                     body = resolve(lines, D, QBS, buf, kb, dma)
-                    chunks.append(f"#define FA2_FWD_BODY_{tag}_B{buf}_K{kb}_M{masked} \\\n" + base.c_string(body) + "\n")
+                    chunks.append(f"#define FA2_FWD_BODY_{tag}_B{buf}_K{kb}_{vtag} \\\n" + base.c_string(body) + "\n")
         assert len(pros) == 1, "every body must leave the same reads in flight for the next one"
         p = resolve(list(pros.pop()), D, QBS, NBUF - 1, R0.NH - 1, False)       # 'next' of the last key block of buffer 3 = (buffer 0, kb 0)
         p.append("s_waitcnt lgkmcnt(0)")
