@@ -328,10 +328,19 @@ def main():
             except Exception as e:
                 box["ring"] = {"error": repr(e)}
 
-        th = threading.Thread(target=ring_leg, daemon=True)
-        th.start()
-        th.join(timeout=float(os.environ.get("FA2_BENCH_RING_TIMEOUT", "180")))
-        hung = th.is_alive()
+        # RCCL prints a version banner on the process's stdout when the environment sets NCCL_DEBUG=VERSION: while the leg runs,
+        # file descriptor 1 points at stderr, so that stdout carries the ONE JSON line and nothing else
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            th = threading.Thread(target=ring_leg, daemon=True)
+            th.start()
+            th.join(timeout=float(os.environ.get("FA2_BENCH_RING_TIMEOUT", "180")))
+            hung = th.is_alive()
+        finally:
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
         if hung:
             out["ring"] = {"error": "ring leg did not finish within its deadline; skipped"}
             out["ring_hang"] = True
