@@ -225,7 +225,9 @@ def resolve(lines, buf, kb, barrier):
     nxt = bases(buf, kb + 1) if kb + 1 < NH else bases((buf + 1) % NBUF, 0)
     out = []
     if barrier:
-        out += ["s_waitcnt vmcnt(0)", "s_barrier"]
+        # FA2_GEN_F8_NOSYNC (timing experiments only -- the results are wrong): 1 = no barrier, 2 = no barrier and no DMA wait
+        nosync = int(os.environ.get("FA2_GEN_F8_NOSYNC", "0"))
+        out += (["s_waitcnt vmcnt(0)"] if nosync < 2 else []) + (["s_barrier"] if nosync < 1 else [])
     for l in lines:
         b = cur
         if l.startswith("@N "):
