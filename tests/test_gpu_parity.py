@@ -238,6 +238,39 @@ def test_forward_step_composes(N, d, P):
         assert np.abs(L.cpu().numpy() - Lr).max() <= 1e-4
 
 
+def test_forward_step_restart_reloads_the_carried_state():
+    """A resumed step (ring step 2 ..) whose rows leave the range the rounds without maxima vouch for runs its row block
+    again (fa2_fwd1_bf16.hip); the second pass must start from the CARRIED (Oacc, l, m), which the first pass has not yet
+    overwritten.  Two shards of 2048 keys; the second holds, past its first tile, a key ~130 natural units above row 1900's
+    reference.  Against the oracle on the whole sequence, both shard orders."""
+    fa, oracle = _fa(), _oracle()
+    B, H, N, d, P = 1, 2, 4096, 128, 2
+    Q, K, V = make(B, H, N, d, 41), make(B, H, N, d, 42), make(B, H, N, d, 43)
+    s = 1.0 / d ** 0.5
+    q = Q.float()[0, 1, 1900]
+    K = K.float()
+    K[0, 1, 2048 + 1500] = q * (130.0 / (s * float(q @ q)))
+    K = K.bfloat16()
+    Qd, Kd, Vd = Q.cuda(), K.cuda(), V.cuda()
+    Or, Lr = oracle.attention_forward(f32(Q), f32(K), f32(V), s)
+    assert Lr[0, 1, 1900] > 120.0
+    cuts = [0, 2048, 4096]
+    for order in ([0, 1], [1, 0]):
+        O = torch.empty_like(Qd)
+        L = torch.empty(B, H, N, device="cuda")
+        Oacc = torch.empty(B, H, N, d, device="cuda")
+        M = torch.empty(B, H, N, device="cuda")
+        for i, blk in enumerate(order):
+            ks = Kd[:, :, cuts[blk]:cuts[blk + 1]].contiguous()
+            vs = Vd[:, :, cuts[blk]:cuts[blk + 1]].contiguous()
+            fa.forward_step(Qd, ks, vs, O, L, Oacc, M, s, first=(i == 0), last=(i == P - 1))
+        torch.cuda.synchronize()
+        assert np.isfinite(f32(O)).all()
+        assert rel(f32(O), Or) <= BF16_REL
+        assert np.abs(L.cpu().numpy() - Lr).max() <= 1e-3
+        assert np.abs(L.cpu().numpy()[0, 0] - Lr[0, 0]).max() <= 1e-4
+
+
 # ----------------------------------------------------------------------------- full-size properties
 def test_full_size_sampled_rows_and_properties():
     """At the bench size (4,16,8192,128) a full oracle pass is ~hours of CPU: check (i) a
