@@ -27,8 +27,10 @@
 // to rounding.  So a workgroup takes the lane maxima during its first tile (which establishes the reference, with the
 // lazy update above) and then runs the X variant of the bodies -- no v_max3_f32 (16 of a body-pair's ~146
 // VALU instructions), no compare.  What the maxima guarded against, a score more than ~60 above the reference, shows in the row
-// sums: if any row of the workgroup ends with l not below 2^80 (or not finite), the workgroup runs its row block again with
-// the maxima in every body (`safe`), as before.  Tail, diagonal and drain bodies keep their maxima either way.
+// sums.  Between two rounds of the ring a row whose sum has passed 2^30 moves its reference up by 64 ln 2 (a slow rise of
+// any size costs nothing); and if any row of the workgroup ends with l not below 2^80 (or not finite) -- a jump of more than
+// ~48 units inside one round -- the workgroup runs its row block again with the maxima in every body (`safe`), as before.
+// Tail, diagonal and drain bodies keep their maxima either way.
 // Measured same-box: (4,16,4096,64) 945 -> ~990 TFLOP/s, (4,16,8192,128) 1.692 -> ~1.65 ms.
 #include <type_traits>
 
@@ -43,6 +45,8 @@ constexpr int kF1Rows = 256;                 // query rows per workgroup (4 wave
 constexpr int kF1Bufs = 4;                  // LDS ring depth (tools/gen_fwd_body.py: NBUF)
 constexpr float kF1RescaleThr = 6.0f;       // natural-log units of the scaled score
 constexpr float kF1SumLimit = 1.2089258e24f; // 2^80: a row sum at or above it sends the workgroup through its row block again, with maxima
+constexpr float kF1LiftAt = 1.0737418e9f;    // 2^30: between two rounds without maxima, a row whose sum has passed it moves its reference up ...
+constexpr float kF1LiftBy = 44.3614196f;     // ... by 64 ln 2 (its sums and O^T scale by 2^-64)
 enum { F1_PLAIN = 0, F1_MASKED = 1, F1_NOMAX = 2 };
 
 typedef __attribute__((address_space(3))) void* f1_lptr_t;
@@ -374,6 +378,37 @@ __device__ __forceinline__ void fa2_fwd1_impl(const FwdArgs& p)
         }
     };
 
+    // Between two rounds without maxima: rows whose sums have outgrown 2^30 -- their scores have risen ~20 units above the
+    // reference the first tile left them -- move their reference up by 64 ln 2, through the same deferred rescale as above.
+    // A slow rise of any size therefore costs nothing; only a jump of more than ~48 units inside one round of the ring ends
+    // in the restart.
+    auto lift = [&]() {
+        bool over[QBS];
+        bool any = false;
+#pragma unroll
+        for (int qb = 0; qb < QBS; ++qb) over[qb] = false;
+        static_for<QBS>([&](auto QB) {
+            constexpr int qb = decltype(QB)::value;
+            over[qb] = half_max(f1_vget<ST + 2 * qb>() + f1_vget<ST + 2 * qb + 1>()) > kF1LiftAt;      // both lanes of a row agree
+            any = any || over[qb];
+        });
+        if (!__any(any)) return;
+        asm volatile("; fa2-cold: row sums past 2^30: references up");
+        update(0);                                        // an O^T rescale still pending goes first
+        static_for<QBS>([&](auto QB) {
+            constexpr int qb = decltype(QB)::value;
+            const float m_new = over[qb] ? m_run[qb] + kF1LiftBy : m_run[qb];
+            const float alpha = over[qb] ? __builtin_amdgcn_exp2f((m_run[qb] - m_new) * kLog2e) : 1.0f;
+            m_run[qb] = m_new;
+            f1_vsetf<QBS, ST_MB + qb>(m_new == -INFINITY ? 0.0f : m_new * kLog2e);
+            f1_vsetf<QBS, ST_TH + qb>((m_new + kF1RescaleThr) * inv_scale);
+            f1_vsetf<QBS, ST + 2 * qb>(f1_vget<ST + 2 * qb>() * alpha);
+            f1_vsetf<QBS, ST + 2 * qb + 1>(f1_vget<ST + 2 * qb + 1>() * alpha);
+            pend[qb] = alpha;
+        });
+        have_pend = true;
+    };
+
     // FLAVOUR 0 / 2: every body of the tile is known to exist and to be unmasked for this wave (no per-body decisions: the
     // only code between two bodies is the test of the flag the body returns), with (0) or without (2) the lane maxima;
     // FLAVOUR 1 = GENERAL: tail, diagonal and drain tiles.
@@ -434,6 +469,7 @@ __device__ __forceinline__ void fa2_fwd1_impl(const FwdArgs& p)
             } else if (t == 0) {             // the first tile establishes the reference
                 run_tile(I0{}, I0{}, t); run_tile(I1{}, I2{}, t + 1); run_tile(I2{}, I2{}, t + 2); run_tile(I3{}, I2{}, t + 3);
             } else {
+                lift();
                 run_tile(I0{}, I2{}, t); run_tile(I1{}, I2{}, t + 1); run_tile(I2{}, I2{}, t + 2); run_tile(I3{}, I2{}, t + 3);
             }
         }

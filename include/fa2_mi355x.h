@@ -87,10 +87,11 @@ int flash_attention(const float* Q, const float* K, const float* V, float* O, fl
 /* O = softmax(scale * Q K^T [+ causal mask]) V ;  L = logsumexp rows.
  * dtype BF16: Q,K,V,O bf16, d in {64,128}.  dtype F32: Q,K,V,O fp32, 1 <= d <= 128.
  * bf16 numerics: a row's softmax reference is set by the first keys it sees (64 at d = 128, 128 at d = 64; lazily, as the
- * reference's running maximum would be) and then left alone -- in fp32 sums and bf16 probabilities a lagging reference changes
- * nothing but rounding.  A 256-row block one of whose rows would leave the safe range that way (its later scores more than
- * ~55 natural units above the reference) is computed a second time with the running maximum followed key block by key
- * block: same results, twice the time for that block.  NaN inputs give NaN outputs. */
+ * reference's running maximum would be) and afterwards only lifted in steps of 64 ln 2 when the row's sum has outgrown 2^30 --
+ * in fp32 sums and bf16 probabilities a lagging reference changes nothing but rounding.  A 256-row block one of whose rows
+ * would leave the safe range that way (scores jumping by more than ~48 natural units within 256 / 512 consecutive keys) is
+ * computed a second time with the running maximum followed key block by key block: same results, twice the time for that
+ * block.  NaN inputs give NaN outputs. */
 int fa2_forward(const void* Q, const void* K, const void* V, void* O, float* L,
                 int B, int H, int seq_len, int head_dim, float softmax_scale,
                 int dtype, int causal, void* stream);

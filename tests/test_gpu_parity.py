@@ -238,6 +238,28 @@ def test_forward_step_composes(N, d, P):
         assert np.abs(L.cpu().numpy() - Lr).max() <= 1e-4
 
 
+@pytest.mark.parametrize("d,causal", [(128, False), (64, True)])
+def test_fwd_scores_rising_along_the_sequence(d, causal):
+    """Scores that climb steadily along the keys -- by ~150 natural units over N = 4096, ~9 per round of the LDS ring: the
+    rows' references follow through the lifts between the rounds without maxima (fa2_fwd1_bf16.hip), no jump is large enough
+    for the restart.  Against the oracle."""
+    fa, oracle = _fa(), _oracle()
+    B, H, N = 1, 2, 4096
+    g = torch.Generator().manual_seed(77)
+    w = torch.ones(d) / d ** 0.5
+    Q = (4.0 * w + (torch.rand(B, H, N, d, generator=g) - 0.5) * 0.2).bfloat16()
+    ramp = (torch.arange(N, dtype=torch.float32) / N)[None, None, :, None]
+    K = (150.0 * d ** 0.5 / 4.0 * ramp * w + (torch.rand(B, H, N, d, generator=g) - 0.5) * 0.2).bfloat16()
+    V = make(B, H, N, d, 78)
+    s = 1.0 / d ** 0.5
+    O, L = fa.flash_attention_2_forward(Q.cuda(), K.cuda(), V.cuda(), s, causal=causal)
+    torch.cuda.synchronize()
+    Or, Lr = oracle.attention_forward(f32(Q), f32(K), f32(V), s, causal=causal)
+    assert Lr.max() > 120.0 and np.isfinite(f32(O)).all() and np.isfinite(L.cpu().numpy()).all()
+    assert rel(f32(O), Or) <= BF16_REL
+    assert np.abs(L.cpu().numpy() - Lr).max() <= 1e-3
+
+
 def test_forward_step_restart_reloads_the_carried_state():
     """A resumed step (ring step 2 ..) whose rows leave the range the rounds without maxima vouch for runs its row block
     again (fa2_fwd1_bf16.hip); the second pass must start from the CARRIED (Oacc, l, m), which the first pass has not yet
