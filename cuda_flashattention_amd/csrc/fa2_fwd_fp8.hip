@@ -132,14 +132,15 @@ __device__ __forceinline__ int f8_pi(int m) { return (m & 3) + 4 * ((m >> 3) & 3
 __global__ void __launch_bounds__(256) fa2_fp8_transpose_kernel(const unsigned char* V, unsigned char* Vt, const unsigned char* K, float* kn,
                                                                 int N, int Npad)
 {
-    __shared__ unsigned char tile[64][kF8D + 4];
+    constexpr int TS = kF8D + 16;                    // tile row pitch: 16-byte aligned rows
+    __shared__ __attribute__((aligned(16))) unsigned char tile[64 * TS];
     __shared__ float wmax[4];
     const int head = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
-    {   // four lanes per key: 32 bytes each
-        const int key = t * 64 + (tid >> 2);
+    const int key = t * 64 + (tid >> 2), part = tid & 3;        // four lanes per key: 32 bytes each
+    {
         float ss = 0.0f;
         if (key < N) {
-            const u32x4* kp = reinterpret_cast<const u32x4*>(K + ((size_t)head * N + key) * kF8D + 32 * (tid & 3));
+            const u32x4* kp = reinterpret_cast<const u32x4*>(K + ((size_t)head * N + key) * kF8D + 32 * part);
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const u32x4 w = kp[c];
@@ -156,22 +157,31 @@ __global__ void __launch_bounds__(256) fa2_fp8_transpose_kernel(const unsigned c
         for (int o = 4; o < 64; o <<= 1) ss = fmaxf(ss, __shfl_xor(ss, o));
         if ((tid & 63) == 0) wmax[tid >> 6] = ss;
     }
-    const unsigned char* Vh = V + (size_t)head * N * kF8D;
-    unsigned char* Vth = Vt + (size_t)head * kF8D * Npad;
-    for (int c = tid; c < 64 * (kF8D / 4); c += 256) {
-        const int row = c / (kF8D / 4), w = c % (kF8D / 4);
-        const int key = t * 64 + row;
-        uint32_t v = 0;
-        if (key < N) v = *reinterpret_cast<const uint32_t*>(Vh + (size_t)key * kF8D + 4 * w);
-        *reinterpret_cast<uint32_t*>(&tile[row][4 * w]) = v;
+    // V rows -> LDS, 16 bytes at a time
+    {
+        u32x4 v0 = {0u, 0u, 0u, 0u}, v1 = v0;
+        if (key < N) {
+            const u32x4* vp = reinterpret_cast<const u32x4*>(V + ((size_t)head * N + key) * kF8D + 32 * part);
+            v0 = vp[0]; v1 = vp[1];
+        }
+        u32x4* dst = reinterpret_cast<u32x4*>(tile + (tid >> 2) * TS + 32 * part);
+        dst[0] = v0; dst[1] = v1;
     }
     __syncthreads();
-    for (int c = tid; c < kF8D * 16; c += 256) {     // 16 words of 4 keys per d row
-        const int dcol = c / 16, w = c % 16;
-        uint32_t v = 0;
+    // out: 16 keys of one d row per task and 16-byte store; four consecutive lanes write one 64-byte run of a V^T row
+    unsigned char* Vth = Vt + (size_t)head * kF8D * Npad;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v |= (uint32_t)tile[4 * w + e][dcol] << (8 * e);
-        *reinterpret_cast<uint32_t*>(Vth + (size_t)dcol * Npad + t * 64 + 4 * w) = v;
+    for (int i = 0; i < 2; ++i) {
+        const int q = tid + 256 * i, chunk = q & 3, dcol = q >> 2;
+        u32x4 o;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v |= (uint32_t)tile[(16 * chunk + 4 * w + e) * TS + dcol] << (8 * e);
+            o[w] = v;
+        }
+        *reinterpret_cast<u32x4*>(Vth + (size_t)dcol * Npad + t * 64 + 16 * chunk) = o;
     }
     if (tid == 0)
         kn[(size_t)head * (Npad / 64) + t] = __builtin_sqrtf(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))) * 1.0002f;
