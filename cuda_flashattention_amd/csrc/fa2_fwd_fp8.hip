@@ -19,9 +19,9 @@
 //     below) that makes those 16 registers the CONSECUTIVE keys 16 h .. 16 h + 15 of the 32-key block.  Packed four to a
 //     register they are k-slots 0..15 (first key block) and 16..31 (second) of the B operand, and the matching A operand
 //     is two plain 16-byte row reads of a V^T tile -- which is why V is transposed once per call into a workspace
-//     ([d][Npad] per head, fa2_fp8_transpose_kernel: 40 us of 2.2 ms at the BASELINE shape).  Reading V through
+//     ([d][Npad] per head, fa2_fp8_transpose_kernel: 34 us of 1.95 ms at the BASELINE shape).  Reading V through
 //     ds_read_b64_tr_b8 instead would take four LDS instructions per fragment where the V^T image takes two: eight more
-//     issue slots per 64 keys and wave in a kernel whose bound is issue slots -- more than the 1.8 % the pass costs.
+//     issue slots per 64 keys and wave in a kernel whose bound is issue slots -- more than the 1.7 % the pass costs.
 //   * P is rounded to e4m3 (v_cvt_pk_fp8_f32) for the second product; with the lazy reference P never exceeds
 //     e^6 = 403 < 448, the largest e4m3 value.  The row sum is taken from the unrounded fp32 p.
 //   * O is written in bf16, L in fp32.  d = 128 only.
