@@ -1,0 +1,49 @@
+"""Dev aid: stress run of the forward kernels (bf16 d = 64 / 128, fp8) against the oracle -- random ragged lengths, causal on and
+off, input amplitudes from flat to peaked, and late keys planted 5 .. 150 natural units above a row's other scores (the
+rounds without maxima, the lifts, the restart; fp8: the rounds the key-norm bound clears or not).
+    python tools/gpu_stress_fwd.py [cases] [seed]"""
+import sys, os, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import cuda_flashattention_amd as fa
+import oracle
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+f = lambda t: t.float().cpu().numpy()
+rel = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b), 1e-30))
+bad = 0
+for i in range(cases):
+    kind = ("bf16_128", "bf16_64", "fp8")[i % 3]
+    d = 64 if kind == "bf16_64" else 128
+    dt = torch.float8_e4m3fn if kind == "fp8" else torch.bfloat16
+    B, H, N = 1, int(rng.integers(1, 4)), int(rng.integers(300, 4500))
+    causal = bool(rng.integers(0, 2))
+    amp = float(rng.choice([0.5, 1.0]) if kind == "fp8" else rng.choice([0.5, 1.0, 3.0]))
+    g = torch.Generator().manual_seed(9000 + i)
+    Q = ((torch.rand(B, H, N, d, generator=g) - 0.5) * amp).to(dt)
+    K = ((torch.rand(B, H, N, d, generator=g) - 0.5) * amp).to(dt).float()
+    V = (torch.rand(B, H, N, d, generator=g) - 0.5).to(dt)
+    s = 1.0 / d ** 0.5
+    spikes = []
+    for _ in range(int(rng.integers(0, 4))):
+        h, key = int(rng.integers(0, H)), int(rng.integers(0, N))
+        row = int(rng.integers(key, N)) if causal else int(rng.integers(0, N))
+        q = Q.float()[0, h, row]
+        mag = float(rng.choice([5.0, 20.0, 45.0, 90.0, 150.0]))
+        kv = q * (mag / (s * float(q @ q)))
+        if kind == "fp8" and float(kv.abs().max()) > 400.0:
+            continue
+        K[0, h, key] = kv
+        spikes.append((h, row, key, mag))
+    K = K.to(dt)
+    O, L = fa.flash_attention_2_forward(Q.cuda(), K.cuda(), V.cuda(), s, causal=causal)
+    torch.cuda.synchronize()
+    Or, Lr = oracle.attention_forward(f(Q), f(K), f(V), s, causal=causal)
+    eo, el = rel(f(O), Or), float(np.abs(L.cpu().numpy() - Lr).max())
+    gate_o = 5e-2 if kind == "fp8" else 5e-3
+    gate_l = 1e-4 if not spikes else (2e-2 if kind == "fp8" else 1e-3)
+    ok = np.isfinite(f(O)).all() and eo <= gate_o and el <= gate_l
+    bad += not ok
+    print(f"{'ok ' if ok else 'BAD'} {kind} H{H} N{N} causal={int(causal)} amp={amp} spikes={spikes}: O {eo:.2e} |dL| {el:.1e}", flush=True)
+print("stress:", "clean" if not bad else f"{bad} BAD")
+sys.exit(1 if bad else 0)
