@@ -193,24 +193,20 @@ def main():
     # counters (fa2_read_clocks: s_memtime / s_memrealtime x 100 MHz)
     sustained = None
     if rank == 0 and not args.no_sustained:
-        lib = fa._capi.lib()
-        clk = torch.zeros(4, dtype=torch.int64, device=dev)
-        cs = torch.cuda.current_stream().cuda_stream
         n_sus = max(args.sustained_steps, 1)
         torch.cuda.synchronize()
-        lib.fa2_read_clocks(clk.data_ptr(), cs)
+        clk0 = fa.ops.read_clocks()
         t0s = time.perf_counter()
         for _ in range(n_sus):
             step()
-        lib.fa2_read_clocks(clk.data_ptr() + 16, cs)
+        clk1 = fa.ops.read_clocks()
         torch.cuda.synchronize()
         dts = time.perf_counter() - t0s
-        c = clk.cpu().tolist()
-        mhz = (c[2] - c[0]) / max(c[3] - c[1], 1) * 100.0
+        mhz = fa.ops.mean_shader_clock_mhz(clk0, clk1)
         sustained = {"steps": n_sus, "seconds": round(dts, 3), "ms_per_step": round(dts / n_sus * 1e3, 4),
                      "tflops": round(14.0 * B * H * N * N * D * n_sus / dts / 1e12, 2),
                      "mean_shader_clock_mhz": round(mhz, 1),
-                     "clock_source": "fa2_read_clocks before/after the window: d(s_memtime) / d(s_memrealtime) x 100 MHz"}
+                     "clock_source": "fa2_read_clocks before/after the window: per XCC d(s_memtime) / d(s_memrealtime) x 100 MHz, mean over the XCCs"}
 
     flops_step = 14.0 * B * H * N * N * D
     ms_per_step = elapsed / args.steps * 1e3
@@ -352,12 +348,14 @@ def main():
     sys.stdout.flush()
     if hung:
         # A wedged transport cannot be interrupted (the worker thread sits inside RCCL): every rank leaves through os._exit.
-        # The headline line is out and says so ("ring_hang": true); the exit status stays 0 -- under torch.distributed.run a
-        # non-zero status of ANY rank makes the launcher kill the others, possibly rank 0 before it has printed -- and the
-        # other ranks give rank 0 a few seconds' head start for the same reason.
+        # The headline line is out and flushed and says so ("ring_hang": true), and rank 0 leaves with a NON-ZERO status so that
+        # a harness that only reads exit codes sees the hang too.  Under torch.distributed.run a non-zero status of any rank
+        # makes the launcher kill the others: the other ranks therefore sleep first (rank 0 is never the one killed early) and
+        # then leave with 0.
         if rank != 0:
             time.sleep(5.0)
-        os._exit(0)
+            os._exit(0)
+        os._exit(3)
     if dist is not None and not args.no_ring:
         # After a ring leg the ranks may disagree on whether it finished (each has its own deadline): no
         # further collective, every rank simply leaves.  The timed region and its barriers are long past.

@@ -25,11 +25,15 @@ namespace fa2 {
 
 typedef __attribute__((address_space(3))) void* fused_lptr_t;
 
-// dS tile [256 keys][32 q] bf16, 64-byte rows of eight 8-byte chunks: chunk c of row r sits at chunk c ^ key(r).  The key
-// may only use row bits 2 and 3 (the E chain steps 16 rows per immediate offset, the packs step 32), which leaves the
-// ds_write_b64 of a 32-lane half two-way conflicted (rows r and r + 16 share a bank pair) and the transposed reads clean.
+// dS tile [256 keys][32 q] bf16, 64-byte rows of eight 8-byte chunks: chunk c of row r sits at chunk c ^ key(r), key(r) = bits
+// 1..3 of r.  A ds_write_b64 is served in four groups of 16 consecutive lanes (= 16 consecutive rows here) against 32 banks
+// of 4 bytes: rows r and r + 2 lie 128 bytes apart, so the eight even (and the eight odd) rows of a group need eight
+// different chunks -- bits 1..3.  The transposed reads (two groups of 32 lanes: four consecutive rows x all eight chunks each)
+// are conflict-free under any per-row permutation of the chunks.  The E chain steps 16 rows per immediate offset and the
+// packs 32, so the key cannot use row bits >= 4, and does not need to.  (Rounds 2-3 used bits 2..3 only: every store two-way
+// conflicted, SQ_LDS_BANK_CONFLICT = 32 cycles per body.)  tools/lds_bank_sim.py checks both access patterns.
 #ifndef FA2_FUSED_DSKEY
-#define FA2_FUSED_DSKEY(row) ((((row) >> 2) & 3) << 1)
+#define FA2_FUSED_DSKEY(row) (((row) >> 1) & 7)
 #endif
 
 #ifndef FA2_FUSED_DIAG        // diagnostic builds (wrong results, timing only): 1 = no waiting, 2 = no running-sum loads, 4 = no stores
@@ -378,6 +382,10 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
         const int first_masked = CAUSAL ? ((n_u - 8) / 6) * 6 : (ragged_unit ? 0 : niter_u);
         auto tl = [&](int u) { return CAUSAL ? ntiles - 1 - u : u; };
         stage(tl(0), 0);
+#ifdef FA2_FUSED_PREFILL      // timing builds whose bodies issue no DMA (tools/gen_fused_body.py, FA2_GEN_ABL=noDMA): every ring slot holds real rows
+        stage(tl(1), 1);
+        stage(tl(2), 2);
+#endif
         fused_dq_zero<DQT>();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                 // V fragments, K image and the first tile have landed
@@ -625,6 +633,12 @@ hipError_t bwd_fused_read_error(const int* ctl, int* err, hipStream_t stream)
     return hipStreamSynchronize(stream);
 }
 
+// a backward on this workspace that runs no hand-off (the two kernels, the atomics form): the error word then says so
+hipError_t bwd_fused_clear_error(int* ctl, hipStream_t stream)
+{
+    return hipMemsetAsync(ctl + kCtlError, 0, sizeof(int), stream);
+}
+
 // (the last 8 ints per unit are only written by -DFA2_FUSED_STATS builds: tools/gpu_stats_fused.py)
 size_t bwd_fused_ctl_bytes(int BH, int N) { return (size_t)(kCtlHeadmap + 16 * (BH + 1) + 9 * BH * ((N + 255) / 256)) * sizeof(int); }
 
@@ -657,6 +671,8 @@ hipError_t launch_bwd_fused_bf16(const BwdArgs& a, float* dQacc, int* ctl, int m
     constexpr int lds = FA2_FUSED_LDS + 16;
     if (mode == 0) {
         e = hipMemsetAsync(dQacc, 0, elems * 4, stream);
+        if (e != hipSuccess) return e;
+        e = bwd_fused_clear_error(ctl, stream);
         if (e != hipSuccess) return e;
         static bool set_f[64] = {};
         e = ensure_dynamic_lds(fa2_bwd_fused_kernel<false, false>, lds, set_f);

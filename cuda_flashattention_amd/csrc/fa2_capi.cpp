@@ -27,10 +27,13 @@ inline int check_common(int B, int H, int N, int d, float scale)
     return FA2_OK;
 }
 
-// bf16 backward only: its two row-constant planes (B H rows floats each) sit behind ONE buffer resource.
+// bf16 backward only: its two row-constant planes (B H rows floats each) sit behind ONE buffer resource.  The single-kernel
+// form builds that resource (and its int offsets) on the length PADDED to a multiple of 256 (fa2_bwd_fused.hip: rc_rsrc,
+// rcoff), so the padded length is what must fit -- for every shape: the 255 rows of slack cost nobody a legitimate problem.
 inline int check_bwd_planes(int B, int H, int rows)
 {
-    return (long long)B * H * rows * 8 > 0x7fffffffLL ? FA2_ERR_INVALID_SHAPE : FA2_OK;
+    const long long padded = ((long long)rows + 255) / 256 * 256;
+    return (long long)B * H * padded * 8 > 0x7fffffffLL ? FA2_ERR_INVALID_SHAPE : FA2_OK;
 }
 
 inline int check_dim(int d, int dtype)
@@ -39,16 +42,6 @@ inline int check_dim(int d, int dtype)
     if (dtype == FA2_DTYPE_F32) return (d >= 1 && d <= 128) ? FA2_OK : FA2_ERR_UNSUPPORTED_HEAD_DIM;
     if (dtype == FA2_DTYPE_FP8_E4M3) return d == 128 ? FA2_OK : FA2_ERR_UNSUPPORTED_HEAD_DIM;
     return FA2_ERR_UNSUPPORTED_DTYPE;
-}
-
-// FA2_FORWARD_PATH=two_wave keeps the bf16 forward on the two-waves-per-SIMD kernel of rounds 1-2 (A/B runs, triage); read once.
-inline hipError_t launch_fwd_bf16_any(const fa2::FwdArgs& a, hipStream_t stream)
-{
-    static const bool two_wave = [] {
-        const char* e = getenv("FA2_FORWARD_PATH");
-        return e && strcmp(e, "two_wave") == 0;
-    }();
-    return two_wave ? fa2::launch_fwd_bf16(a, stream) : fa2::launch_fwd1_bf16(a, stream);
 }
 
 // Grow-only per-device scratch for the reference-signature backward, which has no workspace
@@ -128,7 +121,7 @@ int fa2_forward(const void* Q, const void* K, const void* V, void* O, float* L,
         a.Q = Q; a.K = K; a.V = V; a.O = O; a.L = L; a.Oacc = nullptr; a.M = nullptr;
         a.BH = B * H; a.Nq = seq_len; a.Nk = seq_len; a.d = head_dim; a.scale = softmax_scale;
         a.causal = causal ? 1 : 0; a.causal_shift = 0; a.resume = 0; a.finalize = 1;
-        return hip_status(launch_fwd_bf16_any(a, (hipStream_t)stream));
+        return hip_status(fa2::launch_fwd1_bf16(a, (hipStream_t)stream));
     }
     if (dtype == FA2_DTYPE_FP8_E4M3) {      // workspace from the stream-ordered allocator
         const size_t need = fa2_forward_fp8_workspace_bytes(B, H, seq_len, head_dim);
@@ -262,6 +255,13 @@ int fa2_backward_phases(const void* Q, const void* K, const void* V, const void*
             const FusedWs w = fused_ws((char*)workspace + bwd_base_ws(B, H, seq_len), B, H, seq_len, head_dim);
             return hip_status(fa2::launch_bwd_fused_bf16(a, w.acc, w.ctl, 1, (hipStream_t)stream, w.rcpad));
         }
+        if (fused_ok) {
+            // the workspace has a control block whose error word fa2_backward_status reads: it must describe THIS call, also
+            // when the two kernels run it (FA2_BACKWARD_PATH, a device that is not the validated layout, phases 2 | 4)
+            const FusedWs w = fused_ws((char*)workspace + bwd_base_ws(B, H, seq_len), B, H, seq_len, head_dim);
+            const hipError_t e = fa2::bwd_fused_clear_error(w.ctl, (hipStream_t)stream);
+            if (e != hipSuccess) return hip_status(e);
+        }
         return backward_block_impl(Q, K, V, O, L, dO, dQ, dK, dV, B, H, seq_len, seq_len, head_dim, softmax_scale, dtype, 0, 0, 0,
                                    causal, 0, workspace, workspace_bytes, stream, phases, false);     // phases 6 here = the two kernels
     }
@@ -299,7 +299,10 @@ int fa2_backward_status(const void* workspace, size_t workspace_bytes, int B, in
 {
     if (!workspace) return FA2_ERR_NULL_POINTER;
     if (B <= 0 || H <= 0 || seq_len <= 0) return FA2_ERR_INVALID_SHAPE;
-    if (!bwd_fused_shape(seq_len, head_dim, dtype)) {           // no hand-off, nothing that can time out: only drain the stream
+    // no hand-off, nothing that can time out: only drain the stream.  (A workspace of a single-kernel shape always carries an
+    // error word written by the LAST backward on it -- every launch path clears or sets it -- but where this process never
+    // runs the single kernel, environment or device, there is no reason to trust what the caller's buffer holds.)
+    if (!bwd_fused_shape(seq_len, head_dim, dtype) || !bwd_fused_allowed() || !fa2::bwd_fused_device_ok(nullptr)) {
         return hip_status(hipStreamSynchronize((hipStream_t)stream));
     }
     if (workspace_bytes < fa2_backward_workspace_bytes(B, H, seq_len, head_dim, dtype)) return FA2_ERR_WORKSPACE;
@@ -342,7 +345,8 @@ static int backward_block_impl(const void* Q, const void* K, const void* V, cons
         f.RC = (float*)((char*)workspace + align256((size_t)B * H * q_hs * sizeof(float)));
         f.q_hs = q_hs; f.k_hs = k_hs; f.q_row0 = 0; f.scale = softmax_scale; f.causal = causal ? 1 : 0; f.causal_shift = 0;
         f.phases = 8 | (phases & 1);
-        f.reserve_cus = (phases & FA2_PHASE_LEAVE_ROOM) ? 16 : 0;
+        // bits 8..15: how many CUs to leave (FA2_PHASE_LEAVE_CUS(n)); 0 there = the default of 16
+        f.reserve_cus = (phases & FA2_PHASE_LEAVE_ROOM) ? (((phases >> 8) & 0xff) ? ((phases >> 8) & 0xff) : 16) : 0;
         const FusedWs w = fused_ws((char*)workspace + bwd_base_ws(B, H, q_len), B, H, q_len, head_dim);
         return hip_status(fa2::launch_bwd_fused_bf16(f, w.acc, w.ctl, 1, (hipStream_t)stream, w.rcpad));
     }
@@ -443,7 +447,7 @@ int fa2_forward_step_strided(const void* Q, const void* K, const void* V,
     a.causal = causal ? 1 : 0; a.causal_shift = causal ? causal_shift : 0;
     a.resume = first ? 0 : 1; a.finalize = last ? 1 : 0;
     a.q_hs = q_head_stride; a.k_hs = kv_head_stride;
-    return hip_status(launch_fwd_bf16_any(a, (hipStream_t)stream));
+    return hip_status(fa2::launch_fwd1_bf16(a, (hipStream_t)stream));
 }
 
 int fa2_forward_state_finalize(void* O, float* L, const float* Oacc, const float* M,
@@ -497,10 +501,11 @@ int fa2_accumulate_bf16_2d(float* acc, const void* src, size_t rows, size_t cols
     return hip_status(fa2::launch_accumulate_bf16(acc, src, rows, cols, pitch, init, (hipStream_t)stream));
 }
 
-int fa2_read_clocks(unsigned long long* out2, void* stream)
+int fa2_read_clocks(unsigned long long* out32, void* stream)
 {
-    if (!out2) return FA2_ERR_NULL_POINTER;
-    return hip_status(fa2::launch_read_clocks(out2, (hipStream_t)stream));
+    if (!out32) return FA2_ERR_NULL_POINTER;
+    if ((uintptr_t)out32 & 15) return FA2_ERR_INVALID_SHAPE;
+    return hip_status(fa2::launch_read_clocks(out32, (hipStream_t)stream));
 }
 
 int fa2_fill_f32(float* dst, size_t n, float value, void* stream)

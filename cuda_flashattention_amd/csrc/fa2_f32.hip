@@ -7,7 +7,7 @@
 // 02_backward/main.cu:78-107) and its fp32 gates (1e-4 / 1e-3 / 5e-3) can be met as written.
 // It is the parity path, not the fast path: plain single-buffered LDS tiles, no pipelining.
 //
-// Same algorithm and the same MFMA orientation as the bf16 kernels (fa2_fwd_bf16.hip,
+// Same algorithm and the same MFMA orientation as the bf16 kernels (fa2_fwd1_bf16.hip,
 // fa2_bwd_bf16.hip), with the f32 operand map: one f32 per lane per operand,
 // A[i = lane & 31][k = lane >> 5], B[k = lane >> 5][j = lane & 31], two k per instruction.
 // An accumulator register r of lane-half h is row acc_row(r, h); feeding register r as the B

@@ -28,8 +28,10 @@
 // lazy update above) and then runs the X variant of the bodies -- no v_max3_f32 (16 of a body-pair's ~146
 // VALU instructions), no compare.  What the maxima guarded against, a score more than ~60 above the reference, shows in the row
 // sums.  Between two rounds of the ring a row whose sum has passed 2^30 moves its reference up by 64 ln 2 (a slow rise of
-// any size costs nothing); and if any row of the workgroup ends with l not below 2^80 (or not finite) -- a jump of more than
-// ~48 units inside one round -- the workgroup runs its row block again with the maxima in every body (`safe`), as before.
+// any size costs nothing); and if any row of the workgroup ends with l not below 2^80 (or not finite), or was seen there by
+// one of those moves -- a jump of more than ~48 units inside one round -- the workgroup runs its row block again with the
+// maxima in every body (`safe`), as before.  (What stays outside the contract: |V| beyond ~2^47, where P < 2^80 against a
+// lagging reference can take P V out of fp32 although O itself would fit.)
 // Tail, diagonal and drain bodies keep their maxima either way.
 // Measured same-box: (4,16,4096,64) 945 -> ~990 TFLOP/s, (4,16,8192,128) 1.692 -> ~1.65 ms.
 #include <type_traits>
@@ -382,6 +384,11 @@ __device__ __forceinline__ void fa2_fwd1_impl(const FwdArgs& p)
     // reference the first tile left them -- move their reference up by 64 ln 2, through the same deferred rescale as above.
     // A slow rise of any size therefore costs nothing; only a jump of more than ~48 units inside one round of the ring ends
     // in the restart.
+    // `out_of_range` (per lane, sticky for the pass): a lift scales the sums by 2^-64, which would hide from the check at the
+    // end of the pass that a sum had been at or above 2^80 (or not finite) in between -- P of a key 85 - 88 units above the
+    // lagging reference is ~2^122 - 2^127, finite, and P V leaves fp32 for |V| > 2 while l does not.  So the lift looks
+    // first, and what it sees goes into the restart decision.
+    bool out_of_range = false;
     auto lift = [&]() {
         bool over[QBS];
         bool any = false;
@@ -389,7 +396,9 @@ __device__ __forceinline__ void fa2_fwd1_impl(const FwdArgs& p)
         for (int qb = 0; qb < QBS; ++qb) over[qb] = false;
         static_for<QBS>([&](auto QB) {
             constexpr int qb = decltype(QB)::value;
-            over[qb] = half_max(f1_vget<ST + 2 * qb>() + f1_vget<ST + 2 * qb + 1>()) > kF1LiftAt;      // both lanes of a row agree
+            const float lt = f1_vget<ST + 2 * qb>() + f1_vget<ST + 2 * qb + 1>();      // this lane's half of the row's sum
+            out_of_range = out_of_range || !(lt < kF1SumLimit);                          // also true for NaN / inf
+            over[qb] = half_max(lt) > kF1LiftAt;      // both lanes of a row agree
             any = any || over[qb];
         });
         if (!__any(any)) return;
@@ -459,6 +468,7 @@ __device__ __forceinline__ void fa2_fwd1_impl(const FwdArgs& p)
     bool safe = false;
     for (;;) {
         init_pass();
+        out_of_range = false;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                         // tiles 0 and 1 have landed
         f1_prologue<D, QBS>();
@@ -486,7 +496,7 @@ __device__ __forceinline__ void fa2_fwd1_impl(const FwdArgs& p)
         // Did any row of the WORKGROUP leave the range the X rounds vouch for?  (Every decision here is workgroup-uniform:
         // the restart goes through the tile barriers again.  nfull_wg: the workgroup's last wave has the most full rounds.)
         if (safe || nfull_wg == 0) break;
-        bool bad = false;
+        bool bad = out_of_range;         // a sum seen out of range by a lift, although lifted back since
         static_for<QBS>([&](auto QB) {
             constexpr int qb = decltype(QB)::value;
             bad = bad || !(half_sum(f1_vget<ST + 2 * qb>() + f1_vget<ST + 2 * qb + 1>()) < kF1SumLimit);      // also true for NaN

@@ -28,8 +28,7 @@ struct FwdArgs {
                       // Larger strides address a row range of every head (the zig-zag chunks of the causal ring).
 };
 
-hipError_t launch_fwd_bf16(const FwdArgs& a, hipStream_t stream);      // two waves per SIMD, hand-written stages (rounds 1-2)
-hipError_t launch_fwd1_bf16(const FwdArgs& a, hipStream_t stream);     // one wave per SIMD, generated main loop (round 3)
+hipError_t launch_fwd1_bf16(const FwdArgs& a, hipStream_t stream);     // generated main loop: one wave per SIMD (d = 128), two (d = 64)
 // acc (fp32) = (init) or += src (bf16): `rows` runs of `cols` elements, `pitch` elements apart in both.
 hipError_t launch_accumulate_bf16(float* acc, const void* src, size_t rows, size_t cols, size_t pitch, int init, hipStream_t stream);
 // Ring epilogue: O = bf16(Oacc / l), L = m + ln l for `rows` consecutive rows (l arrives in L).
@@ -78,6 +77,7 @@ bool bwd_fused_device_ok(const char** why);
 // Synchronises `stream` and reads the error word a chained launch leaves in its control block (non-zero: a bounded wait
 // ran out and the output pass turned dQ into NaNs).
 hipError_t bwd_fused_read_error(const int* ctl, int* err, hipStream_t stream);
+hipError_t bwd_fused_clear_error(int* ctl, hipStream_t stream);      // error word <- 0 (a backward on this workspace without a hand-off)
 
 // fp32 family (exact f32 MFMA, any d <= 128, any N): the reference-signature drop-ins.
 struct F32Args {

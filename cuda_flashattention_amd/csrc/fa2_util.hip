@@ -80,7 +80,7 @@ hipError_t launch_bf16_to_f32(const void* src, float* dst, size_t n, hipStream_t
     return hipGetLastError();
 }
 
-// Ring epilogue for the bf16 state layout (fa2_fwd_bf16.hip, STATE kernels): the un-normalised accumulator,
+// Ring epilogue for the bf16 state layout (fa2_fwd1_bf16.hip, STATE kernels): the un-normalised accumulator,
 // the running sum (in L) and the reference maximum become O = acc / l (bf16) and L = m + ln l -- what the
 // last step's finalize switch does, as a pass of its own for schedules in which the last step does not
 // touch every row (causal zig-zag ring).  One thread per 8 columns.
@@ -146,18 +146,28 @@ hipError_t launch_accumulate_bf16(float* acc, const void* src, size_t rows, size
     return hipGetLastError();
 }
 
-// Two 64-bit counters into out[0..1]: s_memtime (ticks of the shader clock) and s_memrealtime (the constant 100 MHz
-// reference).  Two calls bracket a stretch of stream work; d(memtime) / d(memrealtime) x 100 MHz is the mean shader clock
-// the chip held over it (MI355X_MICROARCH.md, DVFS give-back item 6) -- what bench.py's `sustained` object reports.
-__global__ void read_clocks_kernel(unsigned long long* out)
+// Per XCC two 64-bit counters into out[2 x] , out[2 x + 1] (x = HW_REG_XCC_ID, 16 possible values): s_memtime (ticks of the
+// shader clock) and s_memrealtime (the constant 100 MHz reference).  Two calls bracket a stretch of stream work;
+// d(memtime) / d(memrealtime) x 100 MHz PER XCC is the mean shader clock the chip held over it (MI355X_MICROARCH.md, DVFS
+// give-back item 6) -- what bench.py's `sustained` object reports.  Per XCC because s_memtime is an XCC's own counter: a
+// one-workgroup kernel lands on whichever XCC the dispatcher's rotation points at, and two such samples taken on different
+// XCCs differ by the counters' offset, not by elapsed clocks (round 3's rehearsal read "225 MHz" that way as soon as a
+// second process shared the GPU and moved the rotation).  64 workgroups reach every XCC of the device; the workgroups of
+// one XCC write the same slot with 16-byte stores a few hundred clocks apart: any of them will do.
+__global__ void __launch_bounds__(64) read_clocks_kernel(unsigned long long* out)
 {
-    out[0] = __builtin_amdgcn_s_memtime();
-    out[1] = __builtin_amdgcn_s_memrealtime();
+    int xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+    if (threadIdx.x == 0) {
+        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+        const u64x2 v = {__builtin_amdgcn_s_memtime(), __builtin_amdgcn_s_memrealtime()};
+        *reinterpret_cast<u64x2*>(out + 2 * xcc) = v;
+    }
 }
 
 hipError_t launch_read_clocks(unsigned long long* out, hipStream_t stream)
 {
-    hipLaunchKernelGGL(read_clocks_kernel, dim3(1), dim3(1), 0, stream, out);
+    hipLaunchKernelGGL(read_clocks_kernel, dim3(64), dim3(64), 0, stream, out);
     return hipGetLastError();
 }
 

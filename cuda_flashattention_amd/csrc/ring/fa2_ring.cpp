@@ -49,6 +49,7 @@ struct fa2_ring_ctx {
     void* ev_recv[kMaxRanks] = {};
     void* ev_comp[kMaxRanks] = {};
     void* ev_x[kMaxRanks] = {};
+    int reserve_cus = 16;       // fa2_ring_ctx_set_reserved_cus
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -284,6 +285,14 @@ int fa2_ring_ctx_create_with_backend(fa2_ring_ctx** out, const fa2_ring_backend*
     int st = ctx_init_common(c);
     if (st) { fa2_ring_ctx_destroy(c); return st; }
     *out = c;
+    return FA2_OK;
+}
+
+int fa2_ring_ctx_set_reserved_cus(fa2_ring_ctx* c, int n)
+{
+    if (!c) return FA2_ERR_NULL_POINTER;
+    if (n < 1 || n > 255) return FA2_ERR_INVALID_SHAPE;
+    c->reserve_cus = n;
     return FA2_OK;
 }
 
@@ -542,7 +551,7 @@ static int ring_backward_impl(fa2_ring_ctx* c,
     // head of the dQ / dK, dV pieces it defines, and where the dQ rows start.
     // with more than one rank the exchange of the previous step's pieces runs beside the block kernels: the single-kernel
     // form then leaves a few CUs to RCCL (fa2_mi355x.h: FA2_PHASE_LEAVE_ROOM)
-    const int both = 6 | (P > 1 ? FA2_PHASE_LEAVE_ROOM : 0);
+    const int both = 6 | (P > 1 ? FA2_PHASE_LEAVE_CUS(c->reserve_cus) : 0);
     auto block = [&](const void* Kc, const void* Vc, int owner, int par, int* q0, int* nq, int* nk) -> int {
         if (!causal || owner == rank) {
             *q0 = 0; *nq = local_seq_len; *nk = local_seq_len;

@@ -161,3 +161,22 @@ def attention(Q, K, V, softmax_scale=None, causal=False):
     """softmax(scale Q K^T [causal]) V for [B, H, N, d] bf16 (d = 64 | 128) or fp32 (non-causal) device tensors, with gradients.
     A convenience for callers that live in torch autograd; tests and bench.py call the two halves directly."""
     return _Attention.apply(Q, K, V, softmax_scale, causal)
+
+
+def read_clocks(stream=None):
+    """One sample of fa2_read_clocks on `stream`: an int64 device tensor [16][2] = per XCC (shader-clock ticks, 100 MHz
+    reference ticks); rows of XCCs the device does not have stay zero.  Asynchronous: synchronise before reading."""
+    out = torch.zeros(16, 2, dtype=torch.int64, device="cuda")
+    check(_capi.lib().fa2_read_clocks(out.data_ptr(), _stream_ptr(stream)), "fa2_read_clocks")
+    return out
+
+
+def mean_shader_clock_mhz(before, after):
+    """Mean shader clock between two read_clocks samples (the caller has synchronised): per XCC present in both,
+    d(ticks) / d(reference ticks) x 100 MHz; the mean over those XCCs.  s_memtime is an XCC's own counter, so a difference
+    is only ever taken within one XCC."""
+    a, b = before.cpu().tolist(), after.cpu().tolist()
+    vals = [(y[0] - x[0]) / (y[1] - x[1]) * 100.0 for x, y in zip(a, b) if x[1] and y[1] and y[1] > x[1]]
+    if not vals:
+        raise RuntimeError("fa2_read_clocks: no XCC present in both samples")
+    return sum(vals) / len(vals)

@@ -37,6 +37,7 @@ RING_SIGNATURES = {
     "fa2_ring_default_backend": (_i, [_vp]),
     "fa2_ring_ctx_create_with_backend": (_i, [ctypes.POINTER(_vp), _vp, _i, _i]),
     "fa2_ring_ctx_destroy": (_i, [_vp]),
+    "fa2_ring_ctx_set_reserved_cus": (_i, [_vp, _i]),
     "fa2_ring_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "fa2_ring_attention_forward": (_i, [_vp] * 6 + [_i, _i, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp]),
     "fa2_ring_attention_forward_causal": (_i, [_vp] * 6 + [_i, _i, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp]),
@@ -113,6 +114,9 @@ class RingContext:
             ident = ctypes.create_string_buffer(box[0], 128)
         self._h = _vp()
         check(lib.fa2_ring_ctx_create(ctypes.byref(self._h), ident, rank, nranks), "fa2_ring_ctx_create")
+        # CUs the ring backward's block kernels leave to the exchanges beside them: tunable per run, no rebuild
+        if os.environ.get("FA2_RING_RESERVED_CUS"):
+            check(lib.fa2_ring_ctx_set_reserved_cus(self._h, int(os.environ["FA2_RING_RESERVED_CUS"])), "fa2_ring_ctx_set_reserved_cus")
         self._ws = None
 
     def close(self):

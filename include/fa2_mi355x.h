@@ -177,10 +177,13 @@ int fa2_backward_phases(const void* Q, const void* K, const void* V, const void*
  * length that is a multiple of 256 runs the single five-product kernel -- provided the workspace is
  * fa2_backward_workspace_bytes(B, H, q_len, ...) (room for its running sums) and the device is the validated layout
  * (fa2_backward_plan) -- every other block the dQ and dK/dV kernels.  A single bit (2 or 4) always runs that kernel.
- * FA2_PHASE_LEAVE_ROOM (bit 4) asks the single kernel to leave 16 of the device's CUs free: its persistent workgroups fill a
+ * FA2_PHASE_LEAVE_ROOM (bit 4) asks the single kernel to leave some of the device's CUs free: its persistent workgroups fill a
  * CU's register file for the whole launch, so a kernel on another stream that must run CONCURRENTLY (the ring backward's RCCL
- * exchange of the previous step's dK / dV pieces) would otherwise wait for the launch to end.  No effect on the results. */
+ * exchange of the previous step's dK / dV pieces) would otherwise wait for the launch to end.  How many: bits 8..15 of
+ * `phases`, FA2_PHASE_LEAVE_CUS(n) with 1 <= n <= 255; 0 there (plain FA2_PHASE_LEAVE_ROOM) = 16.  A run-time argument, so
+ * that a multi-GPU run can tune it without a rebuild (fa2_ring_ctx_set_reserved_cus).  No effect on the results. */
 #define FA2_PHASE_LEAVE_ROOM 16
+#define FA2_PHASE_LEAVE_CUS(n) (FA2_PHASE_LEAVE_ROOM | (((n) & 0xff) << 8))
 int fa2_backward_block(const void* Q, const void* K, const void* V, const void* O, const float* L,
                        const void* dO, void* dQ, void* dK, void* dV,
                        int B, int H, int q_len, int kv_len, int head_dim, float softmax_scale, int dtype,
@@ -234,10 +237,13 @@ int fa2_accumulate_bf16(float* acc, const void* src, size_t n, int init, void* s
  * src (a row range of every head of a [B][H][N][d] tensor). */
 int fa2_accumulate_bf16_2d(float* acc, const void* src, size_t rows, size_t cols, size_t pitch, int init, void* stream);
 
-/* Measurement aid: a one-thread kernel on `stream` writes two 64-bit device counters to out2 (DEVICE memory, 16 bytes):
- * out2[0] = shader-clock ticks (s_memtime), out2[1] = ticks of the constant 100 MHz reference (s_memrealtime).  Bracket
- * a stretch of work with two calls: d(out2[0]) / d(out2[1]) x 100 MHz is the mean shader clock the chip held over it. */
-int fa2_read_clocks(unsigned long long* out2, void* stream);
+/* Measurement aid: a small kernel on `stream` writes, for every XCC x of the device it reaches (x = HW_REG_XCC_ID < 16), two
+ * 64-bit device counters to out32[2 x], out32[2 x + 1] (DEVICE memory, 32 x 8 = 256 bytes, 16-byte aligned, zeroed by the
+ * caller: an XCC the device does not have keeps zeros): shader-clock ticks (s_memtime: an XCC's own counter, so only
+ * differences taken on the SAME XCC mean anything) and ticks of the constant 100 MHz reference (s_memrealtime).  Bracket a
+ * stretch of work with two calls into two buffers: per XCC, d(ticks) / d(reference ticks) x 100 MHz is the mean shader clock
+ * it held over the stretch (cuda_flashattention_amd.ops.mean_shader_clock_mhz averages the XCCs present in both). */
+int fa2_read_clocks(unsigned long long* out32, void* stream);
 
 /* Element-wise helpers (grid-stride, HBM-bound). */
 int fa2_fill_f32(float* dst, size_t n, float value, void* stream);      /* init_array, cuda_helper.h:60-65 */

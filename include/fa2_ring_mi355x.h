@@ -58,6 +58,12 @@ int fa2_ring_ctx_create_from_comm(fa2_ring_ctx** out, void* nccl_comm, int rank,
 
 int fa2_ring_ctx_destroy(fa2_ring_ctx* ctx);
 
+/* How many CUs the ring backward's single-kernel block launches leave free for the exchanges that run beside them on the
+ * communication stream (fa2_mi355x.h: FA2_PHASE_LEAVE_CUS; only with more than one rank).  1 <= n <= 255; the default is 16
+ * (6 % of the chip) -- a design choice no multi-GPU run has tuned yet, hence a run-time setting.
+ * cuda_flashattention_amd/ring.py sets it from the environment variable FA2_RING_RESERVED_CUS when that is present. */
+int fa2_ring_ctx_set_reserved_cus(fa2_ring_ctx* ctx, int n);
+
 /* ---- backend injection ------------------------------------------------------------------------
  * Everything the ring schedules do to a device goes through this table: ordering (streams and
  * events), the grouped point-to-point transport and the per-step compute.  The product table

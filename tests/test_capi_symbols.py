@@ -15,6 +15,7 @@ def _declared(header):
     text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     text = re.sub(r"//[^\n]*", "", text)
+    text = re.sub(r"^[ \t]*#[^\n]*(\\\n[^\n]*)*", "", text, flags=re.M)      # preprocessor lines (function-like macros are not exports)
     text = re.sub(r"typedef\s+struct\s+\w+\s*\{.*?\}\s*\w+\s*;", "", text, flags=re.S)    # callback tables are not exports
     return sorted(set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", text)))
 
@@ -86,8 +87,8 @@ def test_product_never_touches_oracle():
 def test_product_library_has_no_test_hooks():
     """Fault injection and the forced grid size exist only in tests/loopback/libfa2_mi355x_hooks.so (fa2_bwd_fused.hip built
     -DFA2_TEST_HOOKS); the product library neither exports the setter nor reads the round-2 environment switches, and the
-    only environment variables it reads at all are the two implementation selectors FA2_BACKWARD_PATH and FA2_FORWARD_PATH
-    (once each, cached)."""
+    only environment variable it reads at all is the implementation selector FA2_BACKWARD_PATH (once, cached; the round-3
+    FA2_FORWARD_PATH went with the round-2 forward kernel it selected)."""
     so = os.path.join(ROOT, "cuda_flashattention_amd", "lib", "libfa2_mi355x.so")
     exported = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
     assert "fa2_test_set_fused_hooks" not in exported
@@ -96,7 +97,8 @@ def test_product_library_has_no_test_hooks():
     src = os.path.join(ROOT, "cuda_flashattention_amd", "csrc")
     hits = subprocess.run(["grep", "-rn", "getenv", src, "--include=*.hip", "--include=*.cpp", "--include=*.h"],
                           capture_output=True, text=True).stdout.strip().splitlines()
-    assert len(hits) == 2 and any("FA2_BACKWARD_PATH" in h for h in hits) and any("FA2_FORWARD_PATH" in h for h in hits), hits
+    assert len(hits) == 1 and "FA2_BACKWARD_PATH" in hits[0], hits
+    assert "FA2_FORWARD_PATH" not in strings
     hooks = os.path.join(ROOT, "tests", "loopback", "libfa2_mi355x_hooks.so")
     if os.path.exists(hooks):
         out = subprocess.run(["nm", "-D", "--defined-only", hooks], capture_output=True, text=True, check=True).stdout

@@ -29,7 +29,7 @@ def test_two_rank_bench_line_over_gloo():
     env = dict(os.environ, FA2_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--no-cpu-baseline", "--no-ring", "--sustained-steps", "4"]
+           "--no-cpu-baseline", "--no-ring", "--sustained-steps", "24"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -41,6 +41,6 @@ def test_two_rank_bench_line_over_gloo():
     flops = 14.0 * 4 * 16 * 8192 * 8192 * 128
     assert abs(out["value"] - 2 * flops / (out["ms_per_step"] * 1e-3) / 1e12) <= 0.01 * out["value"]
     assert out["roofline"]["kernel"] and "cpu_baseline" not in out and "ring" not in out
-    # (the clock figure is plumbing here, not a measurement: four steps of two processes time-sharing one GPU read anything
-    # from the idle clock to the sustained one)
-    assert out["sustained"]["steps"] == 4 and out["sustained"]["mean_shader_clock_mhz"] > 0
+    # the clock over the window: taken per XCC (round 3 read "225 MHz" here: its two one-workgroup samples had landed on
+    # different XCCs, whose s_memtime counters have different origins, once a second process moved the dispatcher's rotation)
+    assert out["sustained"]["steps"] == 24 and 500.0 < out["sustained"]["mean_shader_clock_mhz"] < 2600.0

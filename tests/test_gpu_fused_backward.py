@@ -391,6 +391,31 @@ def test_a_lost_progress_word_ends_in_nans_not_in_a_hang():
         assert torch.equal(a, b)
 
 
+def test_status_describes_the_last_backward_on_the_workspace():
+    """fa2_backward_status reads an error word in the workspace: every backward on that workspace must leave it describing
+    ITSELF.  A stale 1 (a fresh torch.empty, or an earlier timed-out launch) followed by a run of the two kernels
+    (fa2_backward_phases(..., 6)) or of the atomics form (fa2_backward_fused mode 0) -- neither has a hand-off -- must read OK,
+    not FA2_ERR_HANDOFF_TIMEOUT."""
+    fa = _fa()
+    lib = fa._capi.lib()
+    B, H, N, d = 1, 2, 1024, 128
+    host, dev, O, L, scale = case(B, H, N, seed=29)
+    nb = lib.fa2_backward_workspace_bytes(B, H, N, d, 0)
+    out = [torch.empty_like(dev[0]) for _ in range(3)]
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for run in ("two_kernel", "atomics"):
+        ws = torch.full((nb,), 0x01, dtype=torch.uint8, device="cuda")        # every int of the control block reads 0x01010101
+        if run == "two_kernel":
+            for ph in (1, 6):
+                assert lib.fa2_backward_phases(P(dev[0]), P(dev[1]), P(dev[2]), P(O), P(L), P(dev[3]), P(out[0]), P(out[1]), P(out[2]),
+                                               B, H, N, d, scale, 0, 0, P(ws), nb, stream, ph) == 0
+        else:
+            assert lib.fa2_backward_fused(P(dev[0]), P(dev[1]), P(dev[2]), P(O), P(L), P(dev[3]), P(out[0]), P(out[1]), P(out[2]),
+                                          B, H, N, d, scale, 0, P(ws), nb, stream) == 0
+        assert lib.fa2_backward_status(P(ws), nb, B, H, N, d, 0, stream) == 0, run
+        assert all(bool(torch.isfinite(t.float()).all()) for t in out)
+
+
 def test_environment_cannot_inject_faults_or_shrink_the_grid(monkeypatch):
     """Round 2's FA2_FUSED_FAULT / FA2_FUSED_GRID environment switches are gone from the product library: setting them
     changes nothing."""

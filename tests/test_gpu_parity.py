@@ -142,6 +142,38 @@ def test_fwd_rounds_without_maxima_late_spikes_and_the_restart(d, causal):
     assert np.abs(L.cpu().numpy()[0, 0] - Lr[0, 0]).max() <= 1e-4
 
 
+@pytest.mark.parametrize("d", [128, 64])
+def test_fwd_spike_just_below_exp_overflow_with_large_values(d):
+    """A late key 86 - 88 natural units above the reference the first tile left (fa2_fwd1_bf16.hip, rounds without maxima):
+    p ~ e^87 = 2^125 is FINITE in fp32 and in bf16, so the row sum stays finite -- but P V leaves fp32 as soon as |V| > ~4,
+    and the next move of the reference (sums x 2^-64) brings the sum back under the 2^80 the end-of-pass check looks for.
+    The moves therefore look at the sums BEFORE scaling them and what they see is sticky for the pass: the row block must run
+    again with maxima and come out finite and right.  |V| up to 6, several full rounds of the ring after the spike, one head
+    with the spike visible to a single row and one with a spike every row sees.  Against the oracle."""
+    fa, oracle = _fa(), _oracle()
+    B, H, N = 1, 3, 4096
+    Q, K = make(B, H, N, d, 41).float(), make(B, H, N, d, 42).float()
+    V = (make(B, H, N, d, 43).float() * 12.0).bfloat16()            # |V| up to 6
+    s = 1.0 / d ** 0.5
+    u = torch.ones(d) / d ** 0.5
+    Q[0, 2] = u + 0.02 * Q[0, 2]                                    # head 2: every row is the unit vector u + 1 % noise
+    Q = Q.bfloat16()
+    Qf = Q.float()
+    q1 = Qf[0, 1, 3000]
+    K[0, 1, 1500] = q1 * (88.0 / (s * float(q1 @ q1)))              # head 1: one row sees 88, the others +-8
+    K[0, 2, 1300] = u * (87.5 / s)                                  # head 2: every row sees 87.5 +- 0.8
+    K = K.bfloat16()
+    O, L = fa.flash_attention_2_forward(Q.cuda(), K.cuda(), V.cuda(), s)
+    torch.cuda.synchronize()
+    Or, Lr = oracle.attention_forward(f32(Q), f32(K), f32(V), s)
+    assert 86.0 < Lr[0, 1, 3000] < 88.7                             # the spikes are what the test says: below the exp overflow
+    assert 86.0 < Lr[0, 2].min() and Lr[0, 2].max() < 88.7
+    assert np.isfinite(f32(O)).all() and np.isfinite(L.cpu().numpy()).all()
+    assert rel(f32(O), Or) <= BF16_REL
+    assert np.abs(L.cpu().numpy() - Lr).max() <= 1e-3
+    assert np.abs(L.cpu().numpy()[0, 0] - Lr[0, 0]).max() <= 1e-4
+
+
 # ----------------------------------------------------------------------------- bf16 backward
 @pytest.mark.parametrize("B,H,N,d,causal", [
     (1, 2, 128, 64, False),

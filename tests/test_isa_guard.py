@@ -27,7 +27,7 @@ CSRC = os.path.join(ROOT, "cuda_flashattention_amd", "csrc")
 def asm():
     subprocess.check_call(["make", "-s", "-j", "4", "-C", CSRC, "asm"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     out = {}
-    for f in ("fa2_fwd_bf16", "fa2_fwd1_bf16", "fa2_bwd_bf16", "fa2_bwd_fused", "fa2_fwd_fp8", "fa2_f32", "fa2_util", "fa1_f32"):
+    for f in ("fa2_fwd1_bf16", "fa2_bwd_bf16", "fa2_bwd_fused", "fa2_fwd_fp8", "fa2_f32", "fa2_util", "fa1_f32"):
         out[f] = open(os.path.join(CSRC, "_obj", f + ".s")).read()
     return out
 
@@ -79,7 +79,7 @@ def _main_loop(body):
     return body[lo:hi]
 
 
-PRODUCT = ("fa2_fwd_bf16", "fa2_fwd1_bf16", "fa2_bwd_bf16", "fa2_bwd_fused", "fa2_fwd_fp8", "fa2_f32", "fa2_util", "fa1_f32")
+PRODUCT = ("fa2_fwd1_bf16", "fa2_bwd_bf16", "fa2_bwd_fused", "fa2_fwd_fp8", "fa2_f32", "fa2_util", "fa1_f32")
 
 
 def test_no_scratch_no_spill(asm):
@@ -93,7 +93,7 @@ def test_no_scratch_no_spill(asm):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("file,pattern", [("fa2_fwd_bf16", "fa2_fwd_bf16_kernel"), ("fa2_fwd1_bf16", "fa2_fwd1_bf16_kernel"),
+@pytest.mark.parametrize("file,pattern", [("fa2_fwd1_bf16", "fa2_fwd1_bf16_kernel"), ("fa2_fwd1_bf16", "fa2_fwd1x2_bf16_kernel"),
                                           ("fa2_bwd_bf16", "fa2_bwd_dq_kernel"),
                                           ("fa2_bwd_bf16", "fa2_bwd_dkdv_kernel"), ("fa2_bwd_fused", "fa2_bwd_fused_kernelILb")])
 def test_accumulator_file_is_touched_by_asm_only(asm, file, pattern):
@@ -207,22 +207,6 @@ def test_fused_backward_kernel(asm):
                 assert sum(s.startswith("s_cbranch_scc1 1b") for s in b) == 1
             else:
                 assert not st and not ld and not dma
-
-
-def test_forward_loop_shape(asm):
-    ks = _kernels(asm["fa2_fwd_bf16"])
-    for D, mfmas in ((128, 96), (64, 48)):          # 3 tiles x 2 half-tile steps x (S^T: D/16 + O^T: D/16) MFMAs
-        for causal in (0, 1):
-            for state in (0, 1):
-                name = next(n for n in ks if f"fa2_fwd_bf16_kernelILi{D}ELb{causal}ELb{state}E" in n)
-                loop = _main_loop(ks[name]["body"])
-                assert sum("v_mfma_f32_32x32x16_bf16" in l for l in loop) == mfmas, name
-                _, blocks = _split_asm(loop)
-                for b in blocks:
-                    if any("v_mfma" in s for s in b):
-                        assert not any(s.startswith("s_nop") for s in b), (name, "s_nop inside an MFMA stage")
-                m = ks[name]["meta"]
-                assert m["agpr"] <= 128 and m["total"] <= 256, (name, m)      # two waves per SIMD
 
 
 def test_backward_loop_shape(asm):

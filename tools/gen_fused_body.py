@@ -4,7 +4,8 @@
 One workgroup = 4 waves = 256 keys of one head (as in fa2_bwd_dkdv_kernel), but the query gradient is formed here too:
 per 32-row sub-tile and wave
 
-    A  S'  = Q K^T - L/scale         2 x 8 MFMAs     K fragments from the K IMAGE in LDS (V moved to resident VGPRs)
+    A  S'  = Q K^T - L/scale         2 x 8 MFMAs     K fragments from the K IMAGE in LDS (V moved to resident VGPRs); the two key
+                                                     blocks' chains alternate, so that one Q fragment read serves both
     B  dP' = dO V^T - D              2 x 8 MFMAs
     E  dQ[q][col] += dS[q][key] K[key][col] of the PREVIOUS sub-tile: 16 MFMAs over all 256 keys of the workgroup for
        this wave's 32 columns -- dS crosses LDS once ([key][q] tile written as the packed pairs already are, read back
@@ -62,6 +63,14 @@ DSB = QRING + 3 * BUFB            # two dS tiles of 256 keys x 32 q bf16
 DSTILE = 256 * 64
 LDS_BYTES = DSB + 2 * DSTILE
 COST = dict(COST, ldsw=6, vmem=10, cmask=8)
+# The body's one barrier sits right behind MFMA number GBAR: everything that must be out before it (the dS tile's writes, the
+# chained form's dQ stores) has a deadline in front of it, everything that relies on it (reads of the next tile, the loads of
+# the next running sum) is released behind it.
+GBAR = int(os.environ.get("FA2_GEN_GBAR", "72"))
+# where the next tile's LDS-DMA pieces may be issued (gaps): the guide prices a piece at ~60 clocks among bare MFMAs, 100 - 185
+# in a phase full of ds_read_b128, 25 - 60 in VALU-only gaps
+DMA_REL = int(os.environ.get("FA2_GEN_DMA_REL", "1"))
+DMA_DL = int(os.environ.get("FA2_GEN_DMA_DL", "12"))
 
 
 def vf(kb, s): b = VF + 4 * (kb * KS + s); return f"v[{b}:{b + 3}]"
@@ -87,6 +96,14 @@ PK = os.environ.get("FA2_GEN_PK", "0") == "1"
 # K image pre-scaled by scale * log2 e (fa2_bwd_fused.hip scales it once per unit): S' arrives in the exp2 domain and the
 # multiply in front of each exponential goes away (32 of a body's ~135 VALU instructions)
 KSCALED = os.environ.get("FA2_GEN_KSCALED", "0") == "1"
+# stage A with the two key blocks' chains interleaved (one Q fragment read per k-step serves both, as one dO fragment does in
+# stage B): 24 instead of 31 ds_read_b128 in the stage whose reads alone fill the LDS array when all four waves are in it
+# (round 4, measured same-box with the dS tile's conflict-free key: 4.313 -> 4.280 ms; FA2_GEN_AILV=0 = the round-3 order)
+AILV = os.environ.get("FA2_GEN_AILV", "1") == "1"
+# ABLATIONS (timing only, WRONG RESULTS; var/ builds for tools/gpu_ab_multi.py): a comma-separated subset of
+#   noE (E's dS / K^T reads), noAK (A's K reads), noDMA (Q / dO / row-constant LDS-DMA), noDQ (running-sum loads and stores),
+#   noVALU (exp / mul / cvt), noDSW (dS tile writes), noRC (row-constant reads), noSEEN (progress prefetch)
+ABL = set(x for x in os.environ.get("FA2_GEN_ABL", "").split(",") if x)
 
 
 def build(chain=False, masked=False):
@@ -113,6 +130,8 @@ def build(chain=False, masked=False):
 
     def rd(text, key, consume, free_after):
         rel = max(consume - READ_AHEAD, free_after + 1)
+        if rel < 0:
+            rel = max(rel, GBAR - NS)            # a read of the NEXT tile: behind this body's barrier
         tasks.append(Task(text, COST["lds"], rel, max(consume - READ_LATEST, rel), "lds", key))
 
     def allocate(rec):
@@ -126,7 +145,18 @@ def build(chain=False, masked=False):
             rd(f"ds_read_b128 {slot(s0)}, v{ROFFK}", ("K", 0, 0), 1, f0)
             mfma[0] = (f"v_mfma_f32_32x32x16_bf16 {sacc(1)}, {slot(sq)}, {slot(s1)}, {sacc(0)}", [("Q", 0, 0), ("K", 1, 0), ("RCS",)])
             mfma[1] = (f"v_mfma_f32_32x32x16_bf16 {sacc(0)}, {slot(sq)}, {slot(s0)}, {sacc(0)}", [("Q", 0, 0), ("K", 0, 0)])
-        for kb in (0, 1):
+        for s in (range(1, KS) if AILV else ()):
+            g = 2 * s
+            a, fa = take(g + 1)
+            b0, f0_ = take(g)
+            b1, f1_ = take(g + 1)
+            if rec:
+                rd(f"ds_read_b128 {slot(a)}, %[r{s}] offset:@Q+0", ("Q", 0, s), g, fa)
+                rd(f"ds_read_b128 {slot(b0)}, v{ROFFK + s}", ("K", 0, s), g, f0_)
+                rd(f"ds_read_b128 {slot(b1)}, v{ROFFK + s} offset:{32 * ROWB}", ("K", 1, s), g + 1, f1_)
+                mfma[g] = (f"v_mfma_f32_32x32x16_bf16 {sacc(0)}, {slot(a)}, {slot(b0)}, {sacc(0)}", [("Q", 0, s), ("K", 0, s)])
+                mfma[g + 1] = (f"v_mfma_f32_32x32x16_bf16 {sacc(1)}, {slot(a)}, {slot(b1)}, {sacc(1)}", [("Q", 0, s), ("K", 1, s)])
+        for kb in (() if AILV else (0, 1)):
             for s in range(1, KS):
                 g = (1 + s) if kb == 0 else (gA1 + s - 1)
                 a, fa = take(g)
@@ -193,7 +223,7 @@ def build(chain=False, masked=False):
 
     last_p, last_d = {}, {}
     for kb in (0, 1):
-        rel_exp = (KS if kb == 0 else 2 * KS - 1) + 3
+        rel_exp = ((2 * KS - 2 + kb) if AILV else (KS if kb == 0 else 2 * KS - 1)) + 3
         exps = {}
         for sp in (0, 1):
             use_pf = gC + 2 * sp * DT + kb
@@ -243,12 +273,12 @@ def build(chain=False, masked=False):
                 # XOR-swizzled by the key; the address register carries the (sp, jp, lane) part, the key block is an immediate)
                 b = DSF + 4 * (2 * kb + sp) + 2 * jp
                 tasks.append(Task(f"ds_write_b64 v{DSWR + 2 * sp + jp}, v[{b}:{b + 1}] offset:@DSW+{kb * 32 * 64}", COST["ldsw"], rel_ds,
-                                  gD + 8, "ldsw", ("dsw", kb, sp, jp), after=cv))
+                                  GBAR - 1, "ldsw", ("dsw", kb, sp, jp), after=cv))
     for g4 in range(4):
         d0 = SACC + 4 * g4
         t = Task(f"ds_read_b128 v[{d0}:{d0 + 3}], %[rc] offset:@RC+{32 * g4}", COST["lds"], -READ_AHEAD - 4, -READ_LATEST, "lds",
                  ("RCS",) if g4 == 3 else ("rcs", g4))
-        t.release = max(t.release, max(last_p[0].deadline, last_p[1].deadline) - NS + 1)
+        t.release = max(t.release, max(last_p[0].deadline, last_p[1].deadline) - NS + 1, GBAR - NS)
         t.deadline = max(t.deadline, t.release)
         tasks.append(t)
     for g4 in range(4):
@@ -272,21 +302,35 @@ def build(chain=False, masked=False):
                 rs = "%[grs]" if which else "%[qrs]"
                 mid = f"s_add_u32 s12, %[qso], {4096 * i}" if i else "s_nop 0"
                 tasks.append(Task(f"s_add_u32 m0, %[mw], @NB+{8192 * which + 4096 * i}\n\t{mid}\n\t"
-                                  f"buffer_load_dwordx4 %[dvo], {rs}, {'s12' if i else '%[qso]'} offen lds", COST["vmem"] + 2, 1, 12, "vmem",
+                                  f"buffer_load_dwordx4 %[dvo], {rs}, {'s12' if i else '%[qso]'} offen lds", COST["vmem"] + 2, DMA_REL, DMA_DL, "vmem",
                                   ("dma", which, i)))
         tasks.append(Task(f"s_cmp_lt_u32 %[wv], 2\n\ts_cbranch_scc0 4f\n\ts_mov_b64 exec, 0xffffffff\n\ts_add_u32 m0, %[mw2], @NB+{2 * 32 * ROWB}\n\t"
-                          "s_nop 0\n\tbuffer_load_dword %[rcvo], %[rcrs], %[rcso] offen lds\n\ts_mov_b64 exec, -1\n\t4:", COST["vmem"] + 6, 1, 12,
+                          "s_nop 0\n\tbuffer_load_dword %[rcvo], %[rcrs], %[rcso] offen lds\n\ts_mov_b64 exec, -1\n\t4:", COST["vmem"] + 6, DMA_REL, DMA_DL,
                           "vmem", ("dma", "rc")))
         # the progress prefetch is issued late (its round trip is ~900 clocks, the barrier behind which it is read sits at
         # gap 72): the staler the prefetched word, the further behind its predecessor a key block has to run
         pg = int(os.environ.get("FA2_GEN_SEEN_GAP", "42"))
         tasks.append(Task("buffer_load_dword v39, off, %[ctl], %[pvo] sc1", COST["vmem"], pg, pg + 4, "vmem", ("seen",)))
         st = [Task(f"buffer_store_dwordx4 v[{DQT + 4 * g}:{DQT + 4 * g + 3}], %[dqv], %[drs], %[dso] offen offset:{1024 * g}", COST["vmem"],
-                   gEend + 3, gEend + 8, "vmem", ("dqst", g)) for g in range(4)]
+                   gEend + 3, min(gEend + 8, GBAR - 1), "vmem", ("dqst", g)) for g in range(4)]
         tasks.extend(st)
         for g in range(4):
             tasks.append(Task(f"buffer_load_dwordx4 v[{DQT + 4 * g}:{DQT + 4 * g + 3}], %[dqv], %[lrs], %[lso] offen offset:{1024 * g}@LDSC",
-                              COST["vmem"], gD + 9, NS - 1, "vmem", ("dqld", g), after=st))
+                              COST["vmem"], GBAR, NS - 1, "vmem", ("dqld", g), after=st))
+    if ABL:
+        def gone(t):
+            k = t.key if isinstance(t.key, tuple) else ()
+            k0 = k[0] if k else None
+            return (("noE" in ABL and k0 in ("ds0", "DS", "kt0", "KT")) or ("noAK" in ABL and k0 == "K") or
+                    ("noDMA" in ABL and k0 == "dma") or ("noDQ" in ABL and k0 in ("dqst", "dqld")) or
+                    ("noVALU" in ABL and t.kind in ("valu", "exp", "cvt", "cmask")) or ("noDSW" in ABL and k0 == "dsw") or
+                    ("noRC" in ABL and k0 in ("rcs", "RCS", "rcd", "RCD")) or ("noSEEN" in ABL and k0 == "seen"))
+        dead = set(id(t) for t in tasks if gone(t))
+        tasks[:] = [t for t in tasks if id(t) not in dead]
+        for t in tasks:
+            t.after = [d for d in t.after if id(d) not in dead]
+        present = set(t.key for t in tasks)
+        mfma = [(text, [k for k in needs if k in present]) for text, needs in mfma]
     return mfma, tasks, NS
 
 
@@ -299,7 +343,7 @@ def render_lines(mfma, per_gap, NS):
     # one s_waitcnt may also cover what the next four MFMAs need, as far as those reads have been in flight for two MFMAs
     # or more: 26 waits per body instead of 56, measured -0.9 % (4.409 -> 4.369 ms; merging younger reads too is slower)
     base.WAIT_LOOK = int(os.environ.get("FA2_GEN_WAIT_LOOK", "4"))
-    base.WAIT_AGE = int(os.environ.get("FA2_GEN_WAIT_AGE", "2"))
+    base.WAIT_AGE = int(os.environ.get("FA2_GEN_WAIT_AGE", "3"))      # round 4: 3 measured 0.6 % faster than 2 beside the interleaved stage A
     return base.render_lines(mfma, per_gap, NS)
 
 
@@ -332,27 +376,19 @@ AFTER_BARRIER = [
 ]
 
 
-def resolve(lines, buf, par, chain=False):
+def resolve(lines, buf, par, chain=False, prologue=False):
     """Body of the sub-tile in ring buffer `buf` whose dS tile is `par`; E reads the previous sub-tile's dS tile (par ^ 1)."""
     lines = [part for l in lines for part in (l.split("\n\t") if not l.startswith("@N ") else [l])]
     def bases(b):
         return {"Q": b * BUFB, "G": b * BUFB + 32 * ROWB, "RC": b * BUFB}
     cur, nxt = bases(buf), bases((buf + 1) % 3)
-    out, barrier_done, e_wait = [], False, False
+    out, barrier_done, e_wait, n_mfma = [], False, False, 0
     for l in lines:
         b = cur
         is_next = l.startswith("@N ")
         if is_next:
             l, b = l[3:], nxt
-            if not barrier_done and l.startswith("ds_read"):
-                # the next tile's DMA (issued in front of this body) has landed, and the chained body's dQ stores are out.
-                # (Letting the stores stay in flight here -- vmcnt(4) -- and publishing one body later was measured: no
-                # faster per step, and a longer start-up skew along the chain.)
-                out.append("s_waitcnt vmcnt(0)")
-                out.append("s_barrier")
-                if chain:
-                    out.extend(AFTER_BARRIER)
-                barrier_done = True
+            assert barrier_done or prologue or not l.startswith("ds_read"), "a read of the next tile in front of the barrier"
         if not e_wait and l.startswith("v_mfma") and l.split()[1].startswith(f"v[{DQT}:"):
             out.append("s_waitcnt vmcnt(%c[vm])")      # the running dQ sum the kernel loaded into DQT ahead of this body has landed
             e_wait = True
@@ -371,7 +407,18 @@ def resolve(lines, buf, par, chain=False):
         l = re.sub(r"@DSW\+(\d+)", lambda m: str(par * DSTILE + int(m.group(1))), l)
         l = re.sub(r"@(Q|G|RC)\+(\d+)", lambda m: str(b[m.group(1)] + int(m.group(2))), l)
         out.append(l)
-    assert barrier_done
+        if l.startswith("v_mfma"):
+            n_mfma += 1
+            if n_mfma == GBAR + 1:
+                # the next tile's DMA (issued in front of this body) has landed, and the chained body's dQ stores are out.
+                # (Letting the stores stay in flight here -- vmcnt(4) -- and publishing one body later was measured: no
+                # faster per step, and a longer start-up skew along the chain.)
+                out.append("s_waitcnt vmcnt(0)")
+                out.append("s_barrier")
+                if chain:
+                    out.extend(AFTER_BARRIER)
+                barrier_done = True
+    assert barrier_done or prologue
     return out
 
 
@@ -408,7 +455,7 @@ def main():
               f"#define FA2_FUSED_DSRD {DSRD}\n#define FA2_FUSED_KT {KT}\n#define FA2_FUSED_QRING {QRING}\n#define FA2_FUSED_BUFB {BUFB}\n"
               f"#define FA2_FUSED_DSB {DSB}\n#define FA2_FUSED_DSTILE {DSTILE}\n#define FA2_FUSED_LDS {LDS_BYTES}\n"
               f"#define FA2_FUSED_SPIN_LIMIT {SPIN_LIMIT}\n"]
-    p = [l for l in resolve(pro, 2, 1) if not l.startswith("s_waitcnt vmcnt") and l != "s_barrier"]      # 'next' of (buffer 2, parity 1) = (0, 0)
+    p = resolve(pro, 2, 1, prologue=True)      # 'next' of (buffer 2, parity 1) = (0, 0)
     p.append("s_waitcnt lgkmcnt(0)")
     chunks.append("#define FA2_FUSED_PRO \\\n" + base.c_string(p) + "\n")
     for buf in range(3):

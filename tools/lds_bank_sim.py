@@ -54,7 +54,71 @@ def tr_read(D, kb, s, jj, dt):
     return out
 
 
+# ---- the dS tile of the single-kernel backward (csrc/fa2_bwd_fused.hip): [256 keys][32 q] bf16, 64-byte rows of eight
+# 8-byte chunks, chunk c of row r at c ^ key(r).  ds_write_b64: four groups of 16 consecutive lanes against 32 banks of 4
+# bytes (MI355X_MICROARCH.md, LDS table); ds_read_b64_tr_b16: two groups of 32 lanes against 64 banks.
+W64_GROUPS = [list(range(16 * g, 16 * g + 16)) for g in range(4)]
+
+
+def ds_key(row):
+    """must match FA2_FUSED_DSKEY in fa2_bwd_fused.hip"""
+    return (row >> 1) & 7
+
+
+def ds_key_round3(row):
+    return ((row >> 2) & 3) << 1
+
+
+def ways_banks(addrs, groups, width, nbanks):
+    worst = 1
+    for g in groups:
+        banks = {}
+        for l in g:
+            for w in range(width // 4):
+                a = addrs[l] + 4 * w
+                banks.setdefault((a // 4) % nbanks, set()).add(a)
+        worst = max(worst, max(len(s) for s in banks.values()))
+    return worst
+
+
+def ds_write(wave, kb, c, key):
+    """packed dS pairs: lane (ki = l & 31, h = l >> 5) stores 8 bytes to chunk (2 c | h) of row 64 wave + 32 kb + ki"""
+    return [(64 * wave + 32 * kb + (l & 31)) * 64 + 8 * (((2 * c) | (l >> 5)) ^ key(l & 31)) for l in range(64)]
+
+
+def ds_tr_read(s, jj, key):
+    """E stage: lane (h, cb, q = (l & 15) >> 2, p = l & 3) reads 8 bytes of row 16 s + 8 jj + 4 h + q, chunk 4 cb + p"""
+    out = []
+    for l in range(64):
+        h, cb, q, p = l >> 5, (l >> 4) & 1, (l & 15) >> 2, l & 3
+        row = 8 * jj + 4 * h + q
+        out.append((16 * s + row) * 64 + 8 * ((4 * cb + p) ^ key(row)))
+    return out
+
+
+def ds_tile(key):
+    w = max(ways_banks(ds_write(wave, kb, c, key), W64_GROUPS, 8, 32) for wave in range(4) for kb in range(2) for c in range(4))
+    r = max(ways_banks(ds_tr_read(s, jj, key), B64_GROUPS, 8, 64) for s in range(16) for jj in range(2))
+    # the reads must find what the writes stored: element (row, q quad) at the same byte under both address forms
+    stored = {}
+    for wave in range(4):
+        for kb in range(2):
+            for c in range(4):
+                for l, a in enumerate(ds_write(wave, kb, c, key)):
+                    stored[a] = (64 * wave + 32 * kb + (l & 31), (2 * c) | (l >> 5))
+    for s in range(16):
+        for jj in range(2):
+            for l, a in enumerate(ds_tr_read(s, jj, key)):
+                h, cb, q, p = l >> 5, (l >> 4) & 1, (l & 15) >> 2, l & 3
+                assert stored[a] == (16 * s + 8 * jj + 4 * h + q, 4 * cb + p), (s, jj, l)
+    return w, r
+
+
 def main():
+    w, r = ds_tile(ds_key)
+    w3, r3 = ds_tile(ds_key_round3)
+    print(f"dS tile: ds_write_b64 worst {w}-way, ds_read_b64_tr_b16 worst {r}-way (round-3 key: {w3}-way / {r3}-way)")
+    assert w == 1 and r == 1 and w3 == 2
     for D in (128, 64):
         w_row = max(ways(row_read(D, kb, s), B128_GROUPS, 16) for kb in range(4) for s in range(D // 16))
         w_tr = max(ways(tr_read(D, kb, s, jj, dt), B64_GROUPS, 8)
