@@ -34,6 +34,7 @@ SIGNATURES = {
     "fa2_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp]),
     "fa2_forward_fp8_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "fa2_forward_fp8": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
+    "fa2_forward_fp8_scaled": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _i, _vp, _sz, _vp]),
     "fa2_backward_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "fa2_backward": (_i, [_vp] * 9 + [_i, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp]),
     "fa2_backward_plan": (_i, [_i, _i, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_char_p)]),

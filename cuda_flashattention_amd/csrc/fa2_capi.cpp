@@ -150,9 +150,23 @@ int fa2_forward_fp8(const void* Q, const void* K, const void* V, void* O, float*
                     int B, int H, int seq_len, int head_dim, float softmax_scale, int causal,
                     void* workspace, size_t workspace_bytes, void* stream)
 {
+    return fa2_forward_fp8_scaled(Q, K, V, O, L, B, H, seq_len, head_dim, softmax_scale, 1.0f, 1.0f, 1.0f, causal, workspace,
+                                  workspace_bytes, stream);
+}
+
+int fa2_forward_fp8_scaled(const void* Q, const void* K, const void* V, void* O, float* L,
+                           int B, int H, int seq_len, int head_dim, float softmax_scale,
+                           float q_descale, float k_descale, float v_descale, int causal,
+                           void* workspace, size_t workspace_bytes, void* stream)
+{
     if (!Q || !K || !V || !O || !L) return FA2_ERR_NULL_POINTER;
+    if (!(q_descale > 0.0f) || !(k_descale > 0.0f) || !(v_descale > 0.0f)) return FA2_ERR_INVALID_SHAPE;
     int st = check_common(B, H, seq_len, head_dim, softmax_scale);
     if (st) return st;
+    // scores are formed from the STORED values: the two descales belong to the softmax scale (the lazy reference, its
+    // thresholds and the key-norm bound are all in units of that product); V's multiplies O once, in the epilogue
+    softmax_scale *= q_descale * k_descale;
+    if (!(softmax_scale > 0.0f) || !(softmax_scale < 3.0e38f)) return FA2_ERR_INVALID_SHAPE;
     st = check_dim(head_dim, FA2_DTYPE_FP8_E4M3);
     if (st) return st;
     if (!workspace || workspace_bytes < fa2_forward_fp8_workspace_bytes(B, H, seq_len, head_dim)) return FA2_ERR_WORKSPACE;
@@ -160,7 +174,7 @@ int fa2_forward_fp8(const void* Q, const void* K, const void* V, void* O, float*
     a.Q = Q; a.K = K; a.V = V; a.Vt = workspace; a.O = O; a.L = L;
     a.BH = B * H; a.N = seq_len; a.Npad = (seq_len + 63) / 64 * 64; a.d = head_dim;
     a.kn = reinterpret_cast<float*>((char*)workspace + (size_t)a.BH * head_dim * a.Npad);
-    a.scale = softmax_scale; a.causal = causal ? 1 : 0;
+    a.scale = softmax_scale; a.causal = causal ? 1 : 0; a.o_scale = v_descale;
     return hip_status(fa2::launch_fwd_fp8(a, (hipStream_t)stream));
 }
 

@@ -452,7 +452,7 @@ __global__ void __launch_bounds__(64 * kF8Waves, 1) __attribute__((amdgpu_num_vg
     mfma_acc_settle();
     const float l_tot = half_sum(f8_vget<ST>() + f8_vget<ST + 1>());
     const size_t qoff = (size_t)head * N + qrow;
-    const float inv = (l_tot > 0.0f ? 1.0f / l_tot : 0.0f) * pend;      // pend: an O rescale still pending from the last update
+    const float inv = (l_tot > 0.0f ? 1.0f / l_tot : 0.0f) * pend * p.o_scale;      // pend: an O rescale still pending from the last update; o_scale: V's descale
     static_for<2 * DT>([&](auto G) {
         constexpr int dt = decltype(G)::value / 2, gp = decltype(G)::value % 2;
         constexpr int R = dt * 16 + 8 * gp;

@@ -44,8 +44,9 @@ struct FwdFp8Args {
     void* O;
     float* L;
     int BH, N, Npad, d;
-    float scale;
+    float scale;      // what multiplies q . k of the STORED e4m3 values: softmax_scale x q_descale x k_descale
     int causal;
+    float o_scale;    // what multiplies O: v_descale (1 = V holds its own values)
 };
 hipError_t launch_fwd_fp8(const FwdFp8Args& a, hipStream_t stream);
 

@@ -674,6 +674,18 @@ size_t fa2_ring_backward_workspace_bytes(int B, int H, int local_seq_len, int he
     return make_bwd_plan(B, H, local_seq_len, head_dim, nranks).total;
 }
 
+int fa2_ring_backward_block_workspace(int B, int H, int local_seq_len, int head_dim, int dtype, int nranks,
+                                      size_t* offset, size_t* bytes)
+{
+    if (!offset || !bytes) return FA2_ERR_NULL_POINTER;
+    if (B <= 0 || H <= 0 || local_seq_len <= 0 || head_dim <= 0 || nranks <= 0) return FA2_ERR_INVALID_SHAPE;
+    if (dtype != FA2_DTYPE_BF16) return FA2_ERR_UNSUPPORTED_DTYPE;
+    const BwdPlan pl = make_bwd_plan(B, H, local_seq_len, head_dim, nranks);
+    *offset = pl.off_ws;
+    *bytes = pl.ws_bytes;
+    return FA2_OK;
+}
+
 int fa2_ring_attention_backward(fa2_ring_ctx* c,
                                 const void* Q_local, const void* K_local, const void* V_local,
                                 const void* O_local, const float* L_local, const void* dO_local,

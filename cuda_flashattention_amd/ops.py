@@ -63,10 +63,18 @@ def _rows(x, name, ref, B, H, N):
     return x
 
 
-def flash_attention_2_forward(Q, K, V, softmax_scale=None, causal=False, O=None, L=None, stream=None):
+def forward_fp8_workspace(B, H, N, d, device="cuda"):
+    """Scratch for the fp8 forward (V transposed + key-norm maxima): allocate once, pass as workspace=."""
+    return torch.empty(_capi.lib().fa2_forward_fp8_workspace_bytes(B, H, N, d), dtype=torch.uint8, device=device)
+
+
+def flash_attention_2_forward(Q, K, V, softmax_scale=None, causal=False, O=None, L=None, stream=None, workspace=None,
+                              descale=None):
     """O, L = FA2 forward.  Mirrors flash_attention_2_forward(Q,K,V,O,L,seq_len,head_dim,scale)
     (reference 02_forward/flash_attention_kernel.cu:300-309) with B,H,dtype,causal,stream added.
-    Tensors [N,d] or [B,H,N,d]; L is fp32 [.., N] natural-log LSE."""
+    Tensors [N,d] or [B,H,N,d]; L is fp32 [.., N] natural-log LSE.  fp8 (e4m3) inputs only: workspace= a caller-owned
+    scratch tensor (forward_fp8_workspace; without it every call takes one from the stream-ordered allocator), descale=
+    (q, k, v) per-tensor descales of tensors stored as x / descale (fa2_forward_fp8_scaled)."""
     B, H, N, d = shape = _bhnd(Q, "Q")
     for n, t in (("K", K), ("V", V)):
         _like(t, n, Q, shape, Q.dtype)
@@ -78,6 +86,19 @@ def flash_attention_2_forward(Q, K, V, softmax_scale=None, causal=False, O=None,
         L = torch.empty(Q.shape[:-1], dtype=torch.float32, device=Q.device)
     _like(O, "O", Q, shape, odt)
     _rows(L, "L", Q, B, H, N)
+    if Q.dtype == torch.float8_e4m3fn and (workspace is not None or descale is not None):
+        if workspace is None:
+            workspace = forward_fp8_workspace(B, H, N, d, Q.device)
+        if not workspace.is_cuda or not workspace.is_contiguous() or workspace.device != Q.device:
+            raise ValueError("workspace must be a contiguous device tensor on Q's device")
+        dq, dk, dv = (1.0, 1.0, 1.0) if descale is None else (float(x) for x in descale)
+        st = _capi.lib().fa2_forward_fp8_scaled(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), L.data_ptr(), B, H, N, d, scale,
+                                                dq, dk, dv, 1 if causal else 0, workspace.data_ptr(),
+                                                workspace.numel() * workspace.element_size(), _stream_ptr(stream))
+        check(st, "fa2_forward_fp8_scaled")
+        return O, L
+    if workspace is not None or descale is not None:
+        raise ValueError("workspace= / descale= belong to the fp8 (float8_e4m3fn) forward")
     st = _capi.lib().fa2_forward(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), L.data_ptr(),
                                  B, H, N, d, scale, _dtype_code(Q), 1 if causal else 0, _stream_ptr(stream))
     check(st, "fa2_forward")

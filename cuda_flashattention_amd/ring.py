@@ -42,6 +42,7 @@ RING_SIGNATURES = {
     "fa2_ring_attention_forward": (_i, [_vp] * 6 + [_i, _i, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp]),
     "fa2_ring_attention_forward_causal": (_i, [_vp] * 6 + [_i, _i, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp]),
     "fa2_ring_backward_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "fa2_ring_backward_block_workspace": (_i, [_i, _i, _i, _i, _i, _i, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
     "fa2_ring_attention_backward": (_i, [_vp] * 10 + [_i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
     "fa2_ring_attention_backward_causal": (_i, [_vp] * 10 + [_i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
     "ring_attention_forward": (_i, [_vp] * 5 + [_i, _i, _i, _f, _vp, _i, _i]),

@@ -107,6 +107,15 @@ size_t fa2_forward_fp8_workspace_bytes(int B, int H, int seq_len, int head_dim);
 int fa2_forward_fp8(const void* Q, const void* K, const void* V, void* O, float* L,
                     int B, int H, int seq_len, int head_dim, float softmax_scale, int causal,
                     void* workspace, size_t workspace_bytes, void* stream);
+/* The same for tensors stored as x / descale (per-tensor scaling, what an fp8 producer that uses e4m3's range hands over):
+ * the scores are softmax_scale (q_descale Q)(k_descale K)^T and O = P (v_descale V).  fa2_forward_fp8 is this call with the
+ * three descales 1 -- i.e. for tensors whose own values fit e4m3 (|x| <= 448); a caller with scaled tensors who uses that
+ * entry point must fold q_descale k_descale into softmax_scale and multiply O by v_descale himself.  L is the log-sum-exp
+ * of the DESCALED scores either way.  Descales must be positive and finite. */
+int fa2_forward_fp8_scaled(const void* Q, const void* K, const void* V, void* O, float* L,
+                           int B, int H, int seq_len, int head_dim, float softmax_scale,
+                           float q_descale, float k_descale, float v_descale, int causal,
+                           void* workspace, size_t workspace_bytes, void* stream);
 
 /* Bytes of scratch fa2_backward needs for this problem: D and the row-constant planes, plus -- for the shapes the
  * single-kernel backward takes (bf16, head_dim 128; see fa2_backward) -- the fp32 running sums of dQ (B H NP head_dim 4 bytes,

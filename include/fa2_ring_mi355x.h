@@ -152,6 +152,11 @@ int fa2_ring_attention_forward_causal(fa2_ring_ctx* ctx,
  * bf16 only.  Workspace: fa2_ring_backward_workspace_bytes.  fa2_ring_attention_backward_causal is the
  * backward of fa2_ring_attention_forward_causal (same zig-zag layout of the local rows). */
 size_t fa2_ring_backward_workspace_bytes(int B, int H, int local_seq_len, int head_dim, int dtype, int nranks);
+/* Where, inside that workspace, the block kernels' own scratch lives (fa2_backward_workspace_bytes(B, H, local_seq_len, ...)
+ * bytes at *offset): after a ring backward has finished, fa2_backward_status(workspace + *offset, *bytes, B, H, local_seq_len,
+ * head_dim, dtype, stream) says whether a hand-off of the single-kernel blocks timed out on this rank (dQ then NaN). */
+int fa2_ring_backward_block_workspace(int B, int H, int local_seq_len, int head_dim, int dtype, int nranks,
+                                      size_t* offset, size_t* bytes);
 int fa2_ring_attention_backward(fa2_ring_ctx* ctx,
                                 const void* Q_local, const void* K_local, const void* V_local,
                                 const void* O_local, const float* L_local, const void* dO_local,

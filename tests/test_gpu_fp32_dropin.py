@@ -203,7 +203,8 @@ def test_fa1_baseline_matches_oracle_medium():
 def test_read_clocks_brackets_a_stretch_of_work():
     """fa2_read_clocks: per XCC two 64-bit device counters (shader-clock ticks -- the XCC's own counter -- and 100 MHz
     reference ticks); two calls around some work give a plausible mean shader clock on every XCC (what bench.py's
-    `sustained` object reports), and the XCCs agree with each other (they share one clock domain)."""
+    `sustained` object reports).  The XCCs need not agree exactly: each holds its own clock (measured on a lightly loaded
+    stretch: 1106 - 1174 MHz across the eight) -- one more reason never to difference counters of two XCCs."""
     import cuda_flashattention_amd as fa
     lib = fa._capi.lib()
     x = torch.rand(4096, 4096, device="cuda")
@@ -219,6 +220,6 @@ def test_read_clocks_brackets_a_stretch_of_work():
     per = [(cb[i][0] - ca[i][0]) / (cb[i][1] - ca[i][1]) * 100.0 for i in present]
     assert all(cb[i][1] > ca[i][1] for i in present)
     assert all(100.0 < m < 2600.0 for m in per), per
-    assert max(per) - min(per) < 0.05 * max(per), per       # one clock domain
+    assert max(per) - min(per) < 0.25 * max(per), per       # eight clock domains, one power budget
     assert abs(fa.ops.mean_shader_clock_mhz(a, b) - sum(per) / 8) < 1e-6
     assert lib.fa2_read_clocks(None, s) == -1

@@ -140,3 +140,33 @@ def test_fp8_unsupported_combinations_are_status_codes():
     with pytest.raises(fa._capi.FA2Error) as e:                                  # fp8 is forward only
         fa.flash_attention_2_backward(Q, Q, Q, O, L, O)
     assert e.value.status == -4
+
+
+def test_fwd_fp8_per_tensor_descales_and_caller_workspace():
+    """fa2_forward_fp8_scaled: tensors stored as x / descale so that they use e4m3's range (here |x| <= 8 stored as |x / d| <=
+    ~400), against the oracle fed the DESCALED rounded values; the same call with descales (1, 1, 1) and a caller workspace is
+    bit-identical to fa2_forward's stream-ordered-allocator path."""
+    fa, oracle = _fa(), _oracle()
+    B, H, N, d = 1, 4, 1024, 128
+    g = torch.Generator().manual_seed(91)
+    amp = (6.0, 5.0, 8.0)
+    X = [((torch.rand(B, H, N, d, generator=g) - 0.5) * 2 * a) for a in amp]
+    desc = [a / 400.0 for a in amp]
+    Q8, K8, V8 = ((x / s).to(torch.float8_e4m3fn) for x, s in zip(X, desc))
+    s = 1.0 / d ** 0.5
+    ws = fa.ops.forward_fp8_workspace(B, H, N, d)
+    for causal in (False, True):
+        O, L = fa.flash_attention_2_forward(Q8.cuda(), K8.cuda(), V8.cuda(), s, causal=causal, workspace=ws, descale=desc)
+        torch.cuda.synchronize()
+        Qr, Kr, Vr = (f32(t) * np.float32(sc) for t, sc in zip((Q8, K8, V8), desc))
+        Or, Lr = oracle.attention_forward(Qr, Kr, Vr, s, causal=causal)
+        assert np.isfinite(f32(O)).all()
+        assert rel(f32(O), Or) <= FP8_REL
+        dl = float(np.abs(L.cpu().numpy() - Lr).max())
+        print(f"fp8 descaled forward causal={causal}: rel-L2(O) {rel(f32(O), Or):.3e}  max|dL| {dl:.3e} at L up to {Lr.max():.1f}")
+        assert dl <= 1e-3          # scores of 25 - 40 natural units here: the gate of the bf16 path's large-score cases
+    Q, K, V = make(B, H, N, d, 1), make(B, H, N, d, 2), make(B, H, N, d, 3)
+    O1, L1 = fa.flash_attention_2_forward(Q.cuda(), K.cuda(), V.cuda(), s)
+    O2, L2 = fa.flash_attention_2_forward(Q.cuda(), K.cuda(), V.cuda(), s, workspace=ws)
+    torch.cuda.synchronize()
+    assert torch.equal(O1, O2) and torch.equal(L1, L2)

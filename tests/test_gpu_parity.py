@@ -156,18 +156,18 @@ def test_fwd_spike_just_below_exp_overflow_with_large_values(d):
     V = (make(B, H, N, d, 43).float() * 12.0).bfloat16()            # |V| up to 6
     s = 1.0 / d ** 0.5
     u = torch.ones(d) / d ** 0.5
-    Q[0, 2] = u + 0.02 * Q[0, 2]                                    # head 2: every row is the unit vector u + 1 % noise
+    Q[0, 2] = u + 0.01 * Q[0, 2]                                    # head 2: every row is the unit vector u + 0.5 % noise
     Q = Q.bfloat16()
     Qf = Q.float()
     q1 = Qf[0, 1, 3000]
     K[0, 1, 1500] = q1 * (88.0 / (s * float(q1 @ q1)))              # head 1: one row sees 88, the others +-8
-    K[0, 2, 1300] = u * (87.5 / s)                                  # head 2: every row sees 87.5 +- 0.8
+    K[0, 2, 1300] = u * (87.5 / s)                                  # head 2: every row sees 87.5 +- 1
     K = K.bfloat16()
     O, L = fa.flash_attention_2_forward(Q.cuda(), K.cuda(), V.cuda(), s)
     torch.cuda.synchronize()
     Or, Lr = oracle.attention_forward(f32(Q), f32(K), f32(V), s)
     assert 86.0 < Lr[0, 1, 3000] < 88.7                             # the spikes are what the test says: below the exp overflow
-    assert 86.0 < Lr[0, 2].min() and Lr[0, 2].max() < 88.7
+    assert 85.5 < Lr[0, 2].min() and Lr[0, 2].max() < 88.7
     assert np.isfinite(f32(O)).all() and np.isfinite(L.cpu().numpy()).all()
     assert rel(f32(O), Or) <= BF16_REL
     assert np.abs(L.cpu().numpy() - Lr).max() <= 1e-3

@@ -193,7 +193,7 @@ def test_ring_forward_baseline_config_at_size_eight_ranks(schedule):
     assert np.isfinite(O).all() and np.isfinite(L).all()
 
 
-def _backward(P, B, H, N, d, causal, seed=0):
+def _backward(P, B, H, N, d, causal, seed=0, keep=False):
     import oracle
     rs, ring, _ = _libs()
     Q, K, V = (_mk((B, H, N, d), seed + i) for i in range(3))
@@ -226,7 +226,7 @@ def _backward(P, B, H, N, d, causal, seed=0):
         for i in range(3):
             got[i][:, :, t["rows"]] = t["outs"][i].float().cpu()
     ref = oracle.attention_backward(f(Q), f(K), f(V), f(dO), float(scale), causal=causal)
-    return [g.numpy() for g in got], ref
+    return [g.numpy() for g in got] + ([loc] if keep else []), ref
 
 
 @pytest.mark.parametrize("causal", [False, True], ids=["plain", "causal"])
@@ -241,6 +241,36 @@ def test_ring_backward(P, causal):
         errs[name] = float(np.linalg.norm(a - b) / np.linalg.norm(b))
     print(f"ring backward P={P} causal={causal}: rel-L2 {errs}")
     assert all(e < 5e-3 for e in errs.values()), errs
+
+
+@pytest.mark.parametrize("causal", [False, True], ids=["plain", "causal"])
+@pytest.mark.parametrize("P,n,H", [(2, 2048, 2), (2, 4096, 2), (4, 2048, 2), (4, 4096, 1)])
+def test_ring_backward_real_local_lengths_single_kernel_chains(P, n, H, causal):
+    """The ring backward at local lengths where a head has 8 / 16 key blocks per rank: the single-kernel blocks' hand-off
+    chains run for real, under FA2_PHASE_LEAVE_CUS (P > 1: a grid of 240 workgroups) and beside the communication stream's
+    copies of the previous step's pieces.  Whole dQ / dK / dV of the gathered sequence against the oracle (the reference's
+    ring test gathers and compares with the one-shot computation, 04_ring_attention.cu:103-142), and on every rank
+    fa2_backward_status on the block kernels' scratch = OK (no hand-off ran out of patience).  (One head at N = 16384: the
+    oracle's O(N^2 d) backward is the cost of this test.)"""
+    rs, ring, _ = _libs()
+    import cuda_flashattention_amd as fa
+    B, d = 1, 128
+    got, ref = _backward(P, B, H, n * P, d, causal, seed=71 + P, keep=True)
+    errs = {}
+    for a, b, name in zip(got[:3], ref, ("dQ", "dK", "dV")):
+        assert np.isfinite(a).all(), name
+        errs[name] = float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    print(f"ring backward P={P} n_local={n} causal={causal}: rel-L2 {errs}")
+    assert all(e < 5e-3 for e in errs.values()), errs
+    off, nb = ctypes.c_size_t(), ctypes.c_size_t()
+    assert ring.fa2_ring_backward_block_workspace(B, H, n, d, BF16, P, ctypes.byref(off), ctypes.byref(nb)) == 0
+    assert nb.value >= fa._capi.lib().fa2_backward_workspace_bytes(B, H, n, d, 0)
+    why = ctypes.c_char_p()
+    assert fa._capi.lib().fa2_backward_plan(B, H, n, d, 0, 0, ctypes.byref(why)) == 1, why.value      # the blocks DO run the single kernel
+    for t in got[3]:
+        st = fa._capi.lib().fa2_backward_status(ctypes.c_void_p(t["ws"].data_ptr() + off.value), nb.value, B, H, n, d, 0,
+                                                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert st == 0, st
 
 
 def test_ring_backward_d64_ragged_local_length():

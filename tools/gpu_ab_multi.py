@@ -26,6 +26,8 @@ from cuda_flashattention_amd import _capi  # noqa: E402  (signatures only; the p
 def load(path):
     h = ctypes.CDLL(os.path.abspath(path), mode=ctypes.RTLD_LOCAL)
     for name, (res, args) in _capi.SIGNATURES.items():
+        if not hasattr(h, name):          # an older variant build without an entry point added since
+            continue
         fn = getattr(h, name)
         fn.restype = res
         fn.argtypes = args
