@@ -140,9 +140,10 @@ __device__ __forceinline__ void fused_dq_zero()
 //   ticket[x]  at 32 x            per-XCD unit queue (x = hardware XCC_ID, 16 possible values)
 //   next_head  at 32 * 16         heads handed out so far, over all XCDs
 //   error      at 32 * 17         set when a bounded spin ran out (the result is then poisoned by the output pass)
-//   headmap[x][k] at 32 * 18 + x (BH + 1) + k   1 + head the k-th chain of queue x works on; -1 = nothing left; 0 = not yet known
+//   headmap[x][k] at 32 * 18 + x (BH + kHmPad) + k   1 + head the k-th chain of queue x works on; -1 = nothing left; 0 = not yet known
 //   prog[head][j] behind it       query sub-tiles whose running dQ sum key block j has completely stored
 constexpr int kCtlTicket = 0, kCtlNextHead = 32 * 16, kCtlError = 32 * 17, kCtlHeadmap = 32 * 18;
+constexpr int kHmPad = 16;           // chains a queue may name past the last head (the causal form takes them in groups of up to 8)
 constexpr int kSpinLimit = FA2_FUSED_SPIN_LIMIT;      // one bound for every wait: the bodies' (generated) and the unit queue's
 
 struct FusedArgs {
@@ -169,7 +170,7 @@ constexpr int g_hook_fault = 0, g_hook_grid = 0;
 #define FA2_HOOK_NOTE_GRID(n) ((void)0)
 #endif
 
-__device__ __forceinline__ int fused_ctl_ints(int BH, int ncb) { return kCtlHeadmap + 16 * (BH + 1) + 9 * BH * ncb; }
+__device__ __forceinline__ int fused_ctl_ints(int BH, int ncb) { return kCtlHeadmap + 16 * (BH + kHmPad) + 9 * BH * ncb; }
 
 __device__ __forceinline__ int fused_load_sc1(const int* p)
 {
@@ -182,6 +183,17 @@ __device__ __forceinline__ int fused_load_sc1(const int* p)
 __device__ __forceinline__ void fused_seen_set(int v)
 {
     asm volatile("v_mov_b32 v39, %0" : : "s"(v) : "v39");
+}
+
+// Inside the unit loop nothing per-lane is kept by the compiler (it has v0..v38): the lane index is recomputed where needed,
+// and the mailbox is read through an address that lives in an SGPR.
+__device__ __forceinline__ int fused_lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+template <int OFF>
+__device__ __forceinline__ int fused_mail_read(uint32_t lds_addr)
+{
+    int v;
+    asm volatile("v_mov_b32 %0, %1\n\tds_read_b32 %0, %0 offset:%c2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "s"(lds_addr), "i"(OFF) : "memory");
+    return __builtin_amdgcn_readfirstlane(v);
 }
 
 // Flags and running sums are written with plain stores: they land in the L2 of this XCD, which is where the readers (same
@@ -235,6 +247,7 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
                   KT = FA2_FUSED_KT;
     constexpr int VMW = CHAIN ? 4 : 63;              // vector-memory operations issued behind the DQT loads and in front of the E chain: >= 4 DMA pieces
     int* const mail = reinterpret_cast<int*>(smem + FA2_FUSED_LDS);      // 16 bytes behind the generated map: the unit taken
+    const uint32_t mail_addr = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem) + FA2_FUSED_LDS;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -285,71 +298,116 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
     if constexpr (CHAIN) {
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
     }
-    int* const prog_base = fp.ctl + kCtlHeadmap + 16 * (p.BH + 1);
+    int* const prog_base = fp.ctl + kCtlHeadmap + 16 * (p.BH + kHmPad);
+    // Units of a queue come in GROUPS of G chains (heads), key-block-major inside a group: ticket u -> group u / (G ncb), key
+    // block j = (u % (G ncb)) / G, chain G group + u % G.  Non-causal: G = 1, a head's key blocks one after the other (all
+    // units are equally long).  Causal: a unit of key block j walks ntiles - 8 j sub-tiles, and with G = 1 the last head of
+    // every queue ended with its LONGEST units started last (a quarter of a CU's whole share each); with a queue's heads taken
+    // together the units come longest first over the group.  G = 2 (BH / 8 if that is less, at least 1 -- the first tickets of
+    // the eight queues must not grab more heads than there are): a larger group balances better but spreads a queue's 32 CUs
+    // over more heads, and a key block that starts long after its predecessor finds that one's running sums gone from the L2.
+    // Measured at (4,16,8192,128) causal, same box: G = 1 2.476 ms, 2 2.406, 4 2.470, 8 2.548.  A unit still only waits for units taken from the same
+    // queue before it (its predecessor (head, j - 1) is G tickets earlier): the deadlock argument is unchanged.
+#ifndef FA2_FUSED_CAUSAL_G
+#define FA2_FUSED_CAUSAL_G 2
+#endif
+    const int G = CAUSAL ? max(1, min(FA2_FUSED_CAUSAL_G, p.BH / 8)) : 1;
     const auto ctl_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)fp.ctl, 0, CHAIN ? fused_ctl_ints(p.BH, ncb) * 4 : 0, 0x00020000);
+
+    // ---- taking a unit (chained form): tid 0 draws tickets from the queue of this XCD until one names a (head, key block) or
+    // the queue is exhausted, and leaves (head | -2, key block, error word) in the mailbox; everybody reads it behind a barrier
+    auto take_ticket = [&]() {
+        if (wave == 0 && fused_lane_id() == 0) {
+            int hd, j = 0;
+            do {
+                const int u = atomicAdd(fp.ctl + kCtlTicket + 32 * xcc, 1);
+                const int r = u % (G * ncb);
+                const int k = (u / (G * ncb)) * G + r % G;
+                j = r / G;
+                hd = -2;                                 // -2: the queue is exhausted; -1: this ticket's chain has no head, the next one may
+                if (k < p.BH + kHmPad) {
+                    int* hm = fp.ctl + kCtlHeadmap + xcc * (p.BH + kHmPad) + k;
+                    int v = 0, spins = 0;
+                    if (j == 0) {
+                        // heads are handed to a queue's chains IN CHAIN ORDER (chain k asks after chain k - 1 has): "chain k
+                        // got none" then means "no later chain of this queue gets one", which is what ends a workgroup
+                        if (k > 0)
+                            while ((v = fused_load_sc1(hm - 1)) == 0)
+                                if (fused_spin_over(fp.ctl, ++spins)) break;
+                        if (k > 0 && v == 0) {
+                            v = -1;                      // a wait ran out (error word raised): nobody takes new work
+                        } else {
+                            const int g = atomicAdd(fp.ctl + kCtlNextHead, 1);
+                            v = g < p.BH ? g + 1 : -1;
+                        }
+                        fused_store_flag(hm, v);
+                    } else {
+                        while ((v = fused_load_sc1(hm)) == 0)
+                            if (fused_spin_over(fp.ctl, ++spins)) { v = -1; break; }
+                    }
+                    // a chain without a head: the first chain of a group ends the queue, any other only this ticket
+                    hd = v > 0 ? v - 1 : (r % G == 0 ? -2 : -1);
+                }
+            } while (hd == -1);
+            mail[0] = hd;
+            mail[1] = j;
+            mail[2] = hd >= 0 ? fused_load_sc1(fp.ctl + kCtlError) : 0;     // somebody's wait ran out: nobody waits any more
+        }
+    };
+    // ---- a unit's operands that live for the whole unit: the V fragments of both key blocks straight into v[VF ...] (B
+    // operands of dP' = dO V^T: lane = key column), and the K image (the workgroup's 256 keys, swizzled like every other
+    // tile: rows for S', columns for dQ) by LDS-DMA: neither passes through compiler-allocated registers.  Issued as soon
+    // as the unit is known -- for every unit but a workgroup's first that is BEFORE the previous unit's epilogue, whose
+    // dK / dV stores then overlap these loads (round 4; the change-over was ticket, loads, stores one after the other).
+    auto issue_unit_loads = [&](int head_, int cb_) {
+        const size_t slab_ = (size_t)head_ * N * ROWB;
+        const char* Kh_ = (const char*)p.K + slab_;
+        const char* Vh_ = (const char*)p.V + slab_;
+        const int kw0_ = cb_ * 256 + wave * 64;
+        const int lane_u = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));    // recomputed: nothing per-lane
+        // (keys past the end of a ragged sequence: any finite row will do -- their P is masked to zero -- so the address
+        // is clamped; everything else reaches them through range-checked buffer resources)
+        const int vk0 = RAGGED ? min(kw0_ + (lane_u & 31), N - 1) : kw0_ + (lane_u & 31);
+        const int vk1 = RAGGED ? min(kw0_ + 32 + (lane_u & 31), N - 1) : kw0_ + 32 + (lane_u & 31);
+        const char* v0 = Vh_ + (size_t)vk0 * ROWB + 16 * (lane_u >> 5);
+        const char* v1 = Vh_ + (size_t)vk1 * ROWB + 16 * (lane_u >> 5);
+        static_for<KS>([&](auto S) { fused_load_vfrag<VF, KS, decltype(S)::value>(v0, v1); });
+        const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kh_, 0, N * ROWB, 0x00020000);
+#pragma unroll
+        for (int j = wave; j < 256 / RPI; j += 4)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (fused_lptr_t)(smem + j * 1024), 16, doff, (cb_ * 256 + j * RPI) * ROWB, 0, 0);
+    };
+
+    // the unit a workgroup is about to work on is what the mailbox says (written behind the previous unit's bodies; nothing is
+    // carried in registers across the epilogue)
+    auto next_unit_loads = [&]() {
+        if constexpr (CHAIN) {
+            take_ticket();
+            __syncthreads();
+            const int hn = fused_mail_read<0>(mail_addr);
+            if (hn >= 0) issue_unit_loads(hn, fused_mail_read<4>(mail_addr));
+        }
+    };
+    next_unit_loads();
 
     for (;;) {
 #ifdef FA2_FUSED_STATS
         const uint64_t s_pull = __builtin_readcyclecounter();
 #endif
-        // ---- the unit: (head, key block)
         int head, cb, err0 = 0;
         if constexpr (CHAIN) {
-            if (tid == 0) {
-                int hd = -1, j = 0;
-                const int u = atomicAdd(fp.ctl + kCtlTicket + 32 * xcc, 1);
-                const int k = u / ncb;
-                j = u % ncb;
-                if (k <= p.BH) {
-                    int* hm = fp.ctl + kCtlHeadmap + xcc * (p.BH + 1) + k;
-                    int v;
-                    if (j == 0) {
-                        const int g = atomicAdd(fp.ctl + kCtlNextHead, 1);
-                        v = g < p.BH ? g + 1 : -1;
-                        fused_store_flag(hm, v);
-                    } else {
-                        int spins = 0;
-                        while ((v = fused_load_sc1(hm)) == 0)
-                            if (fused_spin_over(fp.ctl, ++spins)) { v = -1; break; }
-                    }
-                    hd = v > 0 ? v - 1 : -1;
-                }
-                mail[0] = hd;
-                mail[1] = j;
-                mail[2] = hd >= 0 ? fused_load_sc1(fp.ctl + kCtlError) : 0;     // somebody's wait ran out: nobody waits any more
-            }
-            __syncthreads();
-            head = __builtin_amdgcn_readfirstlane(mail[0]);
-            cb = __builtin_amdgcn_readfirstlane(mail[1]);
-            err0 = __builtin_amdgcn_readfirstlane(mail[2]);
-            if (head < 0) break;
+            head = fused_mail_read<0>(mail_addr);
+            cb = fused_mail_read<4>(mail_addr);
+            err0 = fused_mail_read<8>(mail_addr);
+            if (head < 0) break;                     // the queue is exhausted
         } else {
             map_block(blockIdx.x, p.BH, ncb, head, cb);
+            issue_unit_loads(head, cb);
         }
         const size_t slab = (size_t)head * N * ROWB;
         const char* Qh = (const char*)p.Q + slab;
-        const char* Kh = (const char*)p.K + slab;
-        const char* Vh = (const char*)p.V + slab;
         const char* Gh = (const char*)p.dO + slab;
         const int kw0 = cb * 256 + wave * 64;
-
-        // V fragments of both key blocks straight into v[VF ...] (B operands of dP' = dO V^T: lane = key column), and the K image
-        // (the workgroup's 256 keys, swizzled like every other tile: rows for S', columns for dQ) by LDS-DMA: neither
-        // passes through compiler-allocated registers
-        {
-            const int lane_u = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));    // recomputed: nothing per-lane
-            // (keys past the end of a ragged sequence: any finite row will do -- their P is masked to zero -- so the address
-            // is clamped; everything else reaches them through range-checked buffer resources)
-            const int vk0 = RAGGED ? min(kw0 + (lane_u & 31), N - 1) : kw0 + (lane_u & 31);
-            const int vk1 = RAGGED ? min(kw0 + 32 + (lane_u & 31), N - 1) : kw0 + 32 + (lane_u & 31);
-            const char* v0 = Vh + (size_t)vk0 * ROWB + 16 * (lane_u >> 5);             // is kept (spilled) across units
-            const char* v1 = Vh + (size_t)vk1 * ROWB + 16 * (lane_u >> 5);
-            static_for<KS>([&](auto S) { fused_load_vfrag<VF, KS, decltype(S)::value>(v0, v1); });
-            const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, N * ROWB, 0x00020000);
-#pragma unroll
-            for (int j = wave; j < 256 / RPI; j += 4)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (fused_lptr_t)(smem + j * 1024), 16, doff, (cb * 256 + j * RPI) * ROWB, 0, 0);
-        }
         // dK^T, dV^T <- 0: sixteen MFMAs on a zero fragment instead of 256 accumulator writes
         {
             const u32x4 z = {0u, 0u, 0u, 0u};
@@ -359,7 +417,7 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
         // ---- LDS-DMA staging of a 32-row Q / dO tile + its row constants into ring slot `buf`
         const auto q_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Qh, 0, N * ROWB, 0x00020000);
         const auto g_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Gh, 0, N * ROWB, 0x00020000);
-        const int rcoff = (int)(((wave == 0 ? 0 : rc_plane) + (size_t)head * NP + (lane & 31)) * 4);
+        const int rcoff = (int)(((wave == 0 ? 0 : rc_plane) + (size_t)head * NP + (fused_lane_id() & 31)) * 4);
         auto stage = [&](int t, int buf) {
             char* b = smem + QRING + buf * BUFB;
 #pragma unroll
@@ -369,7 +427,7 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(which ? g_rsrc : q_rsrc, (fused_lptr_t)(b + which * (TROWS * ROWB) + piece * 1024),
                                                          16, doff, soff, 0, 0);
             }
-            if (wave < 2 && lane < 32)                   // 32 x -L/scale (wave 0), 32 x -D (wave 1)
+            if (wave < 2 && fused_lane_id() < 32)        // 32 x -L/scale (wave 0), 32 x -D (wave 1)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rc_rsrc, (fused_lptr_t)(b + 2 * TROWS * ROWB + wave * 128), 4, rcoff, t * TROWS * 4, 0, 0);
         };
         // steps u = 0 .. n_u - 1 of this unit work on sub-tile tl(u); the bodies from `first_masked` on carry the causal mask
@@ -506,10 +564,13 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         if constexpr (CHAIN)
-            if (err && !err0 && tid == 0) atomicExch(fp.ctl + kCtlError, 1);
+            if (err && !err0 && wave == 0 && fused_lane_id() == 0) atomicExch(fp.ctl + kCtlError, 1);
 #ifdef FA2_FUSED_STATS
         const uint64_t s_loop = __builtin_readcyclecounter();
 #endif
+        // ---- the NEXT unit, before this one's epilogue: its ticket, and (behind the barrier that also says every wave is done
+        // with the K image and its V fragments) its K image and V fragments -- they load while dK / dV are being stored
+        next_unit_loads();
 
         mfma_acc_settle();
         // lane indices recomputed here so that nothing per-lane has to live (or spill) across the loop
@@ -520,8 +581,13 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
         static_for<2>([&](auto KB) {
             constexpr int kb = decltype(KB)::value;
             const int key = kw0 + 32 * kb + ki_ep;
-            char* dKk = (char*)p.dK + slab + (size_t)key * ROWB + 16 * h_ep;
-            char* dVk = (char*)p.dV + slab + (size_t)key * ROWB + 16 * h_ep;
+            // (uniform 64-bit bases + ONE 32-bit per-lane offset for both tensors: two 64-bit per-lane pointers are four of
+            // the compiler's 39 registers, and it has none to spare here)
+            char* const dKb = (char*)p.dK + slab;
+            char* const dVb = (char*)p.dV + slab;
+            const uint32_t koff = (uint32_t)key * ROWB + 16u * h_ep;
+            char* dKk = dKb + koff;
+            char* dVk = dVb + koff;
             static_for<2 * DT>([&](auto G) {
                 constexpr int dt = decltype(G)::value / 2, gp = decltype(G)::value % 2;
                 constexpr int RK = 16 * (kb * DT + dt) + 8 * gp, RV = 128 + RK;
@@ -543,7 +609,7 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
             });
         });
 #ifdef FA2_FUSED_STATS
-        if (CHAIN && tid == 0) {                         // debug: ctl[kCtlError + 1 ...] = steps that waited, polls, cycles waited, cycles total
+        if (CHAIN && wave == 0 && fused_lane_id() == 0) {      // debug: ctl[kCtlError + 1 ...] = steps that waited, polls, cycles waited, cycles total
             atomicAdd(fp.ctl + kCtlError + 1, st_steps);
             atomicAdd(fp.ctl + kCtlError + 2, st_polls);
             atomicAdd((unsigned long long*)(fp.ctl + kCtlError + 4), (unsigned long long)st_cycles);
@@ -554,7 +620,7 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
         }
 #endif
         if constexpr (!CHAIN) break;
-        __syncthreads();                                 // the K image and the mailbox are about to be rewritten
+        // (no barrier here: the mailbox is next written behind the next unit's bodies, which are full of barriers)
     }
 }
 
@@ -640,7 +706,7 @@ hipError_t bwd_fused_clear_error(int* ctl, hipStream_t stream)
 }
 
 // (the last 8 ints per unit are only written by -DFA2_FUSED_STATS builds: tools/gpu_stats_fused.py)
-size_t bwd_fused_ctl_bytes(int BH, int N) { return (size_t)(kCtlHeadmap + 16 * (BH + 1) + 9 * BH * ((N + 255) / 256)) * sizeof(int); }
+size_t bwd_fused_ctl_bytes(int BH, int N) { return (size_t)(kCtlHeadmap + 16 * (BH + kHmPad) + 9 * BH * ((N + 255) / 256)) * sizeof(int); }
 
 hipError_t launch_bwd_fused_bf16(const BwdArgs& a, float* dQacc, int* ctl, int mode, hipStream_t stream, float* rcpad)
 {

@@ -218,10 +218,26 @@ __device__ __forceinline__ void fa2_fwd1_impl(const FwdArgs& p)
     const int qi = lane & 31;
     const int h = lane >> 5;
 
+    // Causal (plain launches; the ring's resumable steps keep one row block per workgroup): a workgroup takes TWO row blocks,
+    // nrb - 1 - i and i -- every workgroup the same number of key blocks.  With one row block per workgroup, heaviest first
+    // within a head, the last head of every XCD still ends with its heaviest blocks (a quarter of a CU's whole share each)
+    // started late: 16 % between a launch's first and last finishing CU (round 3).  The pairs keep a head's workgroups
+    // together on one XCD (K / V through its L2), as before.
+    constexpr bool PAIRED = CAUSAL && !STATE;
     const int nrb = (p.Nq + kF1Rows - 1) / kF1Rows;
-    int head, rb;
-    map_block(blockIdx.x, p.BH, nrb, head, rb);
-    if (CAUSAL) rb = nrb - 1 - rb;            // heaviest row-blocks first
+    const int nwg = PAIRED ? (nrb + 1) / 2 : nrb;          // workgroups per head
+    int head, wi;
+    map_block(blockIdx.x, p.BH, nwg, head, wi);
+#pragma nounroll
+    for (int half = 0; half < (PAIRED ? 2 : 1); ++half) {
+    int rb = CAUSAL ? nrb - 1 - wi : wi;              // (not paired) heaviest row blocks first
+    if constexpr (PAIRED) {
+        if (half == 1) {
+            if (wi == nrb - 1 - wi) break;            // odd count: the middle block is its own pair
+            rb = wi;
+            __syncthreads();                          // every wave is done with the first block's last tiles (LDS is re-staged)
+        }
+    }
 
     const int Nq = p.Nq, Nk = p.Nk;
     const size_t qhs = p.q_hs ? p.q_hs : Nq, khs = p.k_hs ? p.k_hs : Nk;
@@ -278,6 +294,9 @@ __device__ __forceinline__ void fa2_fwd1_impl(const FwdArgs& p)
         stage(0, 0);
         stage(1, 1);
         stage(0, 3);          // "the tile before the first": read by the first bodies' P stage (against P = 0): must be finite
+#ifdef FA2_F1_PREFILL         // timing builds whose bodies issue no DMA (tools/gen_fwd_body.py, FA2_GEN_FWD_ABL=noDMA): every ring slot holds real rows
+        stage(2, 2);
+#endif
 #pragma unroll
         for (int qb = 0; qb < QBS; ++qb) pend[qb] = 1.0f;
         have_pend = false;
@@ -549,6 +568,7 @@ __device__ __forceinline__ void fa2_fwd1_impl(const FwdArgs& p)
             }
         }
     });
+    }      // the pair's second row block
 }
 
 // the two shapes as kernels: the register budgets differ (one wave per SIMD: hipcc keeps to v0..v63 of 512 registers; two waves
@@ -572,7 +592,8 @@ template <int D, bool CAUSAL, bool STATE>
 static hipError_t launch_one1(const FwdArgs& a, hipStream_t stream)
 {
     constexpr int lds = 2 * kF1Bufs * 16384 + 16;          // the two rings + the workgroup's restart flag
-    const int nrb = (a.Nq + kF1Rows - 1) / kF1Rows;
+    const int nrb1 = (a.Nq + kF1Rows - 1) / kF1Rows;
+    const int nrb = (CAUSAL && !STATE) ? (nrb1 + 1) / 2 : nrb1;      // plain causal launches: two row blocks per workgroup (fa2_fwd1_impl)
     static bool attr_set[64] = {};
     if constexpr (D == 64 && FA2_FWD64_QBS == 1) {
         auto kern = fa2_fwd1x2_bf16_kernel<D, CAUSAL, STATE>;

@@ -50,6 +50,10 @@ NBUF = 4
 CONFIGS = ((128, 2), (64, 2), (64, 1))
 COST = dict(COST, vmem=12, cmp=8)
 NEG_INF = "0xff800000"
+# ABLATIONS (timing only, WRONG RESULTS; tools/build_fwd_variant.sh + tools/gpu_ab_multi.py): a comma-separated subset of
+#   noFMA / noEXP / noADD / noCVT (that class of the softmax's VALU instructions dropped; expMOV: v_exp_f32 -> v_mov_b32),
+#   noK / noV (the K / V^T fragment reads), noDMA (the next tile's LDS-DMA)
+ABL = set(x for x in os.environ.get("FA2_GEN_FWD_ABL", "").split(",") if x)
 
 
 def kv_of(D):
@@ -172,12 +176,16 @@ def build(D, QBS, par, masked, dma, nomax=False):
                 k += 1
                 pair = []
                 for e, r in enumerate((8 * sp + 2 * j, 8 * sp + 2 * j + 1)):
-                    f = valu(f"v_fma_f32 {R.sreg(op, qb, r)}, {R.sreg(op, qb, r)}, %[c2], -{R.mb(qb)}", "valu", rel, max(dl - 2, rel))
-                    x = valu(f"v_exp_f32 {R.sreg(op, qb, r)}, {R.sreg(op, qb, r)}", "exp", rel, max(dl - 1, rel), after=[f])
-                    valu(f"v_add_f32 {R.l(qb, e)}, {R.l(qb, e)}, {R.sreg(op, qb, r)}", "valu", rel, dl, after=[x])
-                    pair.append(x)
-                valu(f"v_cvt_pk_bf16_f32 {R.pfw(op, qb, sp, j)}, {R.sreg(op, qb, 8 * sp + 2 * j)}, {R.sreg(op, qb, 8 * sp + 2 * j + 1)}",
-                     "cvt", rel, dl, after=pair)
+                    f = None if "noFMA" in ABL else valu(f"v_fma_f32 {R.sreg(op, qb, r)}, {R.sreg(op, qb, r)}, %[c2], -{R.mb(qb)}", "valu", rel, max(dl - 2, rel))
+                    ex = "v_mov_b32" if "expMOV" in ABL else "v_exp_f32"
+                    x = None if "noEXP" in ABL else valu(f"{ex} {R.sreg(op, qb, r)}, {R.sreg(op, qb, r)}", "valu" if "expMOV" in ABL else "exp", rel, max(dl - 1, rel), after=[f] if f else None)
+                    if "noADD" not in ABL:
+                        valu(f"v_add_f32 {R.l(qb, e)}, {R.l(qb, e)}, {R.sreg(op, qb, r)}", "valu", rel, dl, after=[x] if x else None)
+                    if x:
+                        pair.append(x)
+                if "noCVT" not in ABL:
+                    valu(f"v_cvt_pk_bf16_f32 {R.pfw(op, qb, sp, j)}, {R.sreg(op, qb, 8 * sp + 2 * j)}, {R.sreg(op, qb, 8 * sp + 2 * j + 1)}",
+                         "cvt", rel, dl, after=pair)
 
     # ---- lane maxima of block j behind its A chains (masked variant: dead keys to -inf first), then the compare
     last = []
@@ -222,6 +230,14 @@ def build(D, QBS, par, masked, dma, nomax=False):
                 tasks.append(Task(f"s_add_u32 m0, %[mw], @NB+{which * NBUF * TILEB + step * i * 1024}\n\t{so}\n\t"
                                   f"buffer_load_dwordx4 %[dvo], {rs}, {'s12' if i else '%[kso]'} offen lds", COST["vmem"], g0, g0 + 3, "vmem",
                                   ("dma", which, i)))
+    if ABL:
+        def gone(t):
+            k0 = t.key[0] if isinstance(t.key, tuple) else None
+            return ("noK" in ABL and k0 == "K") or ("noV" in ABL and k0 == "VT") or ("noDMA" in ABL and k0 == "dma")
+        dead = set(id(t) for t in tasks if gone(t))
+        tasks[:] = [t for t in tasks if id(t) not in dead]
+        present = set(t.key for t in tasks)
+        mfma = [(text, [k for k in needs if k in present]) for text, needs in mfma]
     return R, mfma, tasks, NS
 
 

@@ -111,23 +111,40 @@ def main():
         bad = [not bool(torch.isfinite(t.float()).all()) for t in outs[n]]
         print(f"{n}: max|diff| vs {names[0]}: " + " ".join(f"{x:.3e}" for x in diffs) + ("  NON-FINITE" if any(bad) else ""), flush=True)
     times = {n: [] for n in names}
+    clocks = {n: [] for n in names}
+    # mean shader clock over each timed block (fa2_read_clocks of the LAST library, which is built from the current source:
+    # per XCC d(s_memtime) / d(s_memrealtime) x 100 MHz, mean over the XCCs) -- separates "fewer cycles" from "a higher clock"
+    rc = libs[-1][1].fa2_read_clocks if hasattr(libs[-1][1], "fa2_read_clocks") else None
     for r in range(a.rounds):
         order = names if r % 2 == 0 else names[::-1]
         for n in order:
+            c0 = torch.zeros(16, 2, dtype=torch.int64, device=dev)
+            c1 = torch.zeros(16, 2, dtype=torch.int64, device=dev)
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
+            if rc:
+                rc(P(c0), cs)
             e0.record()
             for _ in range(a.iters):
                 calls[n]()
             e1.record()
+            if rc:
+                rc(P(c1), cs)
             e1.synchronize()
+            torch.cuda.synchronize()
             times[n].append(e0.elapsed_time(e1) / a.iters)
+            if rc:
+                x, y = c0.cpu().tolist(), c1.cpu().tolist()
+                v = [(q[0] - p_[0]) / (q[1] - p_[1]) * 100.0 for p_, q in zip(x, y) if p_[1] and q[1] > p_[1]]
+                if v:
+                    clocks[n].append(sum(v) / len(v))
     base = statistics.median(times[names[0]])
     print(f"op {op} shape ({B},{H},{N},{d}) causal {causal}: {a.rounds} rounds x {a.iters} launches, interleaved")
     for n in names:
         t = times[n]
         med = statistics.median(t)
-        print(f"  {n:14s} median {med:.4f} ms  min {min(t):.4f}  max {max(t):.4f}   x{med / base:.4f} of {names[0]}", flush=True)
+        ck = f"  clock {statistics.median(clocks[n]):7.1f} MHz  Mcycles {med * statistics.median(clocks[n]) / 1e3:7.3f}" if clocks[n] else ""
+        print(f"  {n:14s} median {med:.4f} ms  min {min(t):.4f}  max {max(t):.4f}   x{med / base:.4f} of {names[0]}{ck}", flush=True)
 
 
 if __name__ == "__main__":

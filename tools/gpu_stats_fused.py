@@ -22,7 +22,7 @@ print(f"error={int(ctl[e])} units={units} steps that waited={steps} ({steps/unit
 print(f"cycles waited/unit={cyc(4)/units:.0f} total/unit={cyc(6)/units:.0f}")
 import numpy as np
 ncb = N // 256
-rec = ctl[32*18 + 16*(B*H+1) + B*H*ncb:][:8*units].numpy().reshape(B*H, ncb, 8)
+rec = ctl[32*18 + 16*(B*H+16) + B*H*ncb:][:8*units].numpy().reshape(B*H, ncb, 8)
 t0 = rec[..., 4:6].copy().view(np.int64)[..., 0]; t1 = rec[..., 6:8].copy().view(np.int64)[..., 0]
 base = t0.min()
 dur = (t1 - t0)
