@@ -118,7 +118,11 @@ __device__ __forceinline__ void fused_dq_atomic(__amdgpu_buffer_rsrc_t rs, uint3
 template <int VF, int KS, int S>
 __device__ __forceinline__ void fused_load_vfrag(const char* v0, const char* v1)
 {
-    asm volatile("global_load_dwordx4 v[%c2:%c3], %0, off offset:%c4\n\tglobal_load_dwordx4 v[%c5:%c6], %1, off offset:%c4"
+#ifndef FA2_FUSED_KV_NT       // experiment: once-read K / V rows (and the dK / dV stores) with the streaming cache policy
+#define FA2_FUSED_KV_NT ""
+#define FA2_FUSED_KV_AUX 0
+#endif
+    asm volatile("global_load_dwordx4 v[%c2:%c3], %0, off offset:%c4" FA2_FUSED_KV_NT "\n\tglobal_load_dwordx4 v[%c5:%c6], %1, off offset:%c4" FA2_FUSED_KV_NT
                  : : "v"(v0), "v"(v1), "i"(VF + 4 * S), "i"(VF + 4 * S + 3), "i"(32 * S), "i"(VF + 4 * (KS + S)), "i"(VF + 4 * (KS + S) + 3)
                  : "memory", "v255");
 }
@@ -233,10 +237,15 @@ __device__ __forceinline__ bool fused_spin_over(int* ctl, int spins)
 //     workgroup walking 256 steps alone.)
 // RAGGED (chained forms): seq_len is not a multiple of 256 -- loops, running-sum layout and row-constant planes are built on
 // the padded length fp.npad; a separate instantiation, so that the kernels of the aligned shapes carry none of it.
-template <bool CHAIN, bool CAUSAL, bool RAGGED = false>
+// RECT (chained, non-causal, aligned; round 4): a RECTANGULAR, head-strided block -- Nq query rows (a multiple of 32) of every
+// head, heads q_hs rows apart, the first of them row q_row0 of the dense row-constant planes, against Nk keys (a multiple of
+// 256), heads k_hs rows apart: the unmasked half blocks of the zig-zag causal ring's backward.  Its own instantiation too: the
+// square kernels keep one length in one register.
+template <bool CHAIN, bool CAUSAL, bool RAGGED = false, bool RECT = false>
 __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) fa2_bwd_fused_kernel(FusedArgs fp)
 {
     static_assert(CHAIN || !RAGGED, "the atomics form has no ragged variant");
+    static_assert(!RECT || (CHAIN && !CAUSAL && !RAGGED), "rectangular blocks: chained, unmasked, aligned");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const BwdArgs& p = fp.b;
     constexpr int D = 128, ROWB = 256, KS = 8, DT = 4;
@@ -254,13 +263,17 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ki = lane & 31;
     const int h = lane >> 5;
-    const int N = p.Nk;                          // square, dense: Nq == Nk == q_hs == k_hs; the TRUE length (tensor ranges, stores)
+    const int N = p.Nk;                          // keys: the TRUE length (tensor ranges, stores).  Square: == Nq == q_hs == k_hs
     const int NP = RAGGED ? fp.npad : N;         // the length the loops, the running-sum layout and the planes are built on
+    const int NQ = RECT ? p.Nq : N;              // query rows (RECT: a multiple of 32)
+    const int NPQ = RECT ? NQ : NP;
+    const int QHS = RECT ? p.q_hs : N, KHS = RECT ? p.k_hs : N;      // rows between consecutive heads, query side / key side
+    const int QR0 = RECT ? p.q_row0 : 0;         // the block's first row in the dense row-constant planes
     const int ncb = NP / 256;
-    const int ntiles = NP / TROWS;
+    const int ntiles = NPQ / TROWS;
     const int niter = ((ntiles + 1 + 5) / 6) * 6;        // bodies come in sixes (ring of 3 x dS parity); the extra ones see zero rows
     const float c2 = p.scale * kLog2e;
-    const size_t rc_plane = (size_t)p.BH * NP;
+    const size_t rc_plane = (size_t)p.BH * (RECT ? QHS : NP);
 
     // ---- loop-invariant LDS addresses
     const uint32_t lbase = (uint32_t)(uintptr_t)smem;
@@ -360,7 +373,7 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
     // as the unit is known -- for every unit but a workgroup's first that is BEFORE the previous unit's epilogue, whose
     // dK / dV stores then overlap these loads (round 4; the change-over was ticket, loads, stores one after the other).
     auto issue_unit_loads = [&](int head_, int cb_) {
-        const size_t slab_ = (size_t)head_ * N * ROWB;
+        const size_t slab_ = (size_t)head_ * KHS * ROWB;
         const char* Kh_ = (const char*)p.K + slab_;
         const char* Vh_ = (const char*)p.V + slab_;
         const int kw0_ = cb_ * 256 + wave * 64;
@@ -375,7 +388,7 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
         const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kh_, 0, N * ROWB, 0x00020000);
 #pragma unroll
         for (int j = wave; j < 256 / RPI; j += 4)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (fused_lptr_t)(smem + j * 1024), 16, doff, (cb_ * 256 + j * RPI) * ROWB, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (fused_lptr_t)(smem + j * 1024), 16, doff, (cb_ * 256 + j * RPI) * ROWB, 0, FA2_FUSED_KV_AUX);
     };
 
     // the unit a workgroup is about to work on is what the mailbox says (written behind the previous unit's bodies; nothing is
@@ -404,7 +417,7 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
             map_block(blockIdx.x, p.BH, ncb, head, cb);
             issue_unit_loads(head, cb);
         }
-        const size_t slab = (size_t)head * N * ROWB;
+        const size_t slab = (size_t)head * QHS * ROWB;
         const char* Qh = (const char*)p.Q + slab;
         const char* Gh = (const char*)p.dO + slab;
         const int kw0 = cb * 256 + wave * 64;
@@ -415,9 +428,9 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
         }
 
         // ---- LDS-DMA staging of a 32-row Q / dO tile + its row constants into ring slot `buf`
-        const auto q_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Qh, 0, N * ROWB, 0x00020000);
-        const auto g_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Gh, 0, N * ROWB, 0x00020000);
-        const int rcoff = (int)(((wave == 0 ? 0 : rc_plane) + (size_t)head * NP + (fused_lane_id() & 31)) * 4);
+        const auto q_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Qh, 0, NQ * ROWB, 0x00020000);
+        const auto g_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Gh, 0, NQ * ROWB, 0x00020000);
+        const int rcoff = (int)(((wave == 0 ? 0 : rc_plane) + (size_t)head * (RECT ? QHS : NP) + QR0 + (fused_lane_id() & 31)) * 4);
         auto stage = [&](int t, int buf) {
             char* b = smem + QRING + buf * BUFB;
 #pragma unroll
@@ -449,7 +462,7 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
         __syncthreads();                                 // V fragments, K image and the first tile have landed
         asm volatile(FA2_FUSED_PRO : : FA2_FUSED_OPS, [vm] "i"(VMW) : FA2_FUSED_CLOBBERS);
 
-        const auto dq_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(fp.dQacc + (size_t)head * NP * D), 0, NP * D * 4, 0x00020000);
+        const auto dq_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(fp.dQacc + (size_t)head * NPQ * D), 0, NPQ * D * 4, 0x00020000);
         int* const mine = prog_base + head * ncb + cb;
         const int* const prev = mine - 1;                             // the key block this one takes the running sums from
         const int prev_off = (int)((prev - fp.ctl) * 4);
@@ -583,8 +596,9 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
             const int key = kw0 + 32 * kb + ki_ep;
             // (uniform 64-bit bases + ONE 32-bit per-lane offset for both tensors: two 64-bit per-lane pointers are four of
             // the compiler's 39 registers, and it has none to spare here)
-            char* const dKb = (char*)p.dK + slab;
-            char* const dVb = (char*)p.dV + slab;
+            const size_t slab_k = RECT ? (size_t)head * KHS * ROWB : slab;
+            char* const dKb = (char*)p.dK + slab_k;
+            char* const dVb = (char*)p.dV + slab_k;
             const uint32_t koff = (uint32_t)key * ROWB + 16u * h_ep;
             char* dKk = dKb + koff;
             char* dVk = dVb + koff;
@@ -600,7 +614,11 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
                     const auto s0 = __builtin_amdgcn_permlane32_swap(x[0], y[0], false, false);
                     const auto s1 = __builtin_amdgcn_permlane32_swap(x[1], y[1], false, false);
                     const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+#ifdef FA2_FUSED_ST_NT
+                    if (!RAGGED || key < N) __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(dst + 2 * (32 * dt + 16 * gp)));
+#else
                     if (!RAGGED || key < N) *reinterpret_cast<u32x4*>(dst + 2 * (32 * dt + 16 * gp)) = o;      // (ragged: keys past the end)
+#endif
                 };
                 emit(pack4(acc_read<RK>(), acc_read<RK + 1>(), acc_read<RK + 2>(), acc_read<RK + 3>(), p.scale),
                      pack4(acc_read<RK + 4>(), acc_read<RK + 5>(), acc_read<RK + 6>(), acc_read<RK + 7>(), p.scale), dKk);
@@ -640,9 +658,10 @@ __global__ void __launch_bounds__(256) fa2_bwd_fused_dq_out_kernel(const float* 
 }
 
 // the same for the chained kernel's layout: slot i = (((head * NP / 32 + tile) * 4 + wave) * 4 + g) * 64 + lane holds rows
-// 32 tile + 8 g + 4 (lane >> 5) + (0 .. 3) of column 32 wave + (lane & 31); NP = N rounded up to 256, rows >= N are not stored
+// 32 tile + 8 g + 4 (lane >> 5) + (0 .. 3) of column 32 wave + (lane & 31); NP = N rounded up to 256, rows >= N are not stored;
+// consecutive heads of dQ are qhs rows apart (N, or a rectangular block's head stride)
 __global__ void __launch_bounds__(256) fa2_bwd_fused_dq_out_chain_kernel(const float* __restrict__ acc, __bf16* __restrict__ dQ, size_t n4, float scale,
-                                                                          const int* __restrict__ err, int N, int NP)
+                                                                          const int* __restrict__ err, int N, int NP, int qhs)
 {
     const float poison = *err ? __builtin_nanf("") : 0.0f;
     const size_t stride = (size_t)gridDim.x * 256;
@@ -652,7 +671,7 @@ __global__ void __launch_bounds__(256) fa2_bwd_fused_dq_out_chain_kernel(const f
         const int lane = (int)(i & 63), g = (int)((i >> 6) & 3), wave = (int)((i >> 8) & 3);
         const size_t tg = i >> 10, head = tg / tiles;
         const int row = (int)(tg % tiles) * 32 + 8 * g + 4 * (lane >> 5);
-        __bf16* o = dQ + (head * (size_t)N + row) * 128 + 32 * wave + (lane & 31);
+        __bf16* o = dQ + (head * (size_t)qhs + row) * 128 + 32 * wave + (lane & 31);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             if (row + e < N) o[(size_t)e * 128] = (__bf16)(a[e] * scale + poison);
@@ -712,7 +731,12 @@ hipError_t launch_bwd_fused_bf16(const BwdArgs& a, float* dQacc, int* ctl, int m
 {
     const int npad = (a.Nk + 255) / 256 * 256;
     const bool ragged = npad != a.Nk;            // chained form only: needs `rcpad` (2 BH npad floats)
-    if (a.d != 128 || a.Nq != a.Nk || a.Nk < 1 || a.q_hs != a.Nq || a.k_hs != a.Nk || a.q_row0 != 0) return hipErrorInvalidValue;
+    // a rectangular and / or head-strided block (fa2_backward_block: the causal ring's unmasked half blocks): chained form,
+    // no mask, both lengths aligned; everything else is the dense square problem
+    const bool rect = a.Nq != a.Nk || a.q_hs != a.Nq || a.k_hs != a.Nk || a.q_row0 != 0;
+    if (a.d != 128 || a.Nk < 1 || a.Nq < 1) return hipErrorInvalidValue;
+    if (rect && (mode != 1 || a.causal || ragged || a.Nq % 32 != 0 || a.q_row0 < 0 || a.q_hs < a.q_row0 + a.Nq || a.k_hs < a.Nk))
+        return hipErrorInvalidValue;
     if (ragged && (mode != 1 || !rcpad)) return hipErrorInvalidValue;
     if (a.causal && (mode != 1 || a.causal_shift != 0)) return hipErrorInvalidValue;
     if (mode == 1 && (a.phases & 8) && !bwd_fused_device_ok(nullptr)) return hipErrorNotSupported;
@@ -724,7 +748,7 @@ hipError_t launch_bwd_fused_bf16(const BwdArgs& a, float* dQacc, int* ctl, int m
         if (e != hipSuccess) return e;
     }
     if (!(a.phases & 8)) return hipSuccess;
-    const size_t elems = (size_t)a.BH * npad * 128;
+    const size_t elems = (size_t)a.BH * (rect ? a.Nq : npad) * 128;
     const int units = a.BH * (npad / 256);
     if (ragged) {
         const size_t n = (size_t)2 * a.BH * npad;
@@ -767,8 +791,12 @@ hipError_t launch_bwd_fused_bf16(const BwdArgs& a, float* dQacc, int* ctl, int m
         if (g_hook_grid >= 1 && g_hook_grid < wgs) wgs = g_hook_grid;
         FA2_HOOK_NOTE_GRID(wgs);
         const dim3 grid((unsigned)wgs);
-        static bool set_cr[64] = {}, set_tr[64] = {};
-        if (a.causal && ragged) {
+        static bool set_cr[64] = {}, set_tr[64] = {}, set_re[64] = {};
+        if (rect) {
+            e = ensure_dynamic_lds(fa2_bwd_fused_kernel<true, false, false, true>, lds, set_re);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((fa2_bwd_fused_kernel<true, false, false, true>), grid, dim3(256), lds, stream, fa);
+        } else if (a.causal && ragged) {
             e = ensure_dynamic_lds(fa2_bwd_fused_kernel<true, true, true>, lds, set_cr);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL((fa2_bwd_fused_kernel<true, true, true>), grid, dim3(256), lds, stream, fa);
@@ -793,7 +821,7 @@ hipError_t launch_bwd_fused_bf16(const BwdArgs& a, float* dQacc, int* ctl, int m
                            (const int*)nullptr);
     else
         hipLaunchKernelGGL(fa2_bwd_fused_dq_out_chain_kernel, dim3(4096), dim3(256), 0, stream, dQacc, (__bf16*)a.dQ, elems / 4, a.scale,
-                           ctl + kCtlError, a.Nk, npad);
+                           ctl + kCtlError, rect ? a.Nq : a.Nk, rect ? a.Nq : npad, rect ? a.q_hs : a.Nk);
     return hipGetLastError();
 }
 

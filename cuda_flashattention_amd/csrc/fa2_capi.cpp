@@ -350,19 +350,33 @@ static int backward_block_impl(const void* Q, const void* K, const void* V, cons
     // and the local causal block) IS a problem the single five-product kernel takes -- L being the log-sum-exp over more
     // keys than the block's changes nothing for it.  Taken when both main kernels are asked for at once (phases 6 or 7),
     // the workspace has room for its running sums and the device is the validated layout; otherwise the two kernels.
-    if (allow_single && (phases & 6) == 6 && q_len == kv_len && q_hs == q_len && k_hs == kv_len && q_row0 == 0 &&
-        (!causal || causal_shift == 0) && bwd_fused_shape(q_len, head_dim, dtype) && bwd_fused_allowed() &&
-        workspace_bytes >= fa2_backward_workspace_bytes(B, H, q_len, head_dim, dtype) && fa2::bwd_fused_device_ok(nullptr)) {
+    // Round 4: so is an UNMASKED rectangular, head-strided block whose lengths are aligned (q_len a multiple of 32 and at least
+    // 512, kv_len a multiple of 256) -- the other two block shapes of the zig-zag causal ring.  The workspace layout is the
+    // square problem's for q_hs rows (planes, running sums, control block -- fa2_backward_status finds its word in one place),
+    // so kv_len must not exceed what its control block was sized for.
+    const bool square = q_len == kv_len && q_hs == q_len && k_hs == kv_len && q_row0 == 0 && (!causal || causal_shift == 0) &&
+                        bwd_fused_shape(q_len, head_dim, dtype);
+    const bool rect = !square && !causal && head_dim == 128 && q_len % 32 == 0 && q_len >= 512 && kv_len % 256 == 0 &&
+                      kv_len <= fused_npad(q_hs) && bwd_fused_shape(q_hs, head_dim, dtype);
+    if (allow_single && (phases & 6) == 6 && (square || rect) && bwd_fused_allowed() &&
+        workspace_bytes >= fa2_backward_workspace_bytes(B, H, q_hs, head_dim, dtype) && fa2::bwd_fused_device_ok(nullptr)) {
         fa2::BwdArgs f{};
         f.Q = Q; f.K = K; f.V = V; f.O = O; f.dO = dO; f.L = L; f.dQ = dQ; f.dK = dK; f.dV = dV;
         f.D = (float*)workspace; f.BH = B * H; f.Nq = q_len; f.Nk = kv_len; f.d = head_dim;
         f.RC = (float*)((char*)workspace + align256((size_t)B * H * q_hs * sizeof(float)));
-        f.q_hs = q_hs; f.k_hs = k_hs; f.q_row0 = 0; f.scale = softmax_scale; f.causal = causal ? 1 : 0; f.causal_shift = 0;
+        f.q_hs = q_hs; f.k_hs = k_hs; f.q_row0 = q_row0; f.scale = softmax_scale; f.causal = causal ? 1 : 0; f.causal_shift = 0;
         f.phases = 8 | (phases & 1);
         // bits 8..15: how many CUs to leave (FA2_PHASE_LEAVE_CUS(n)); 0 there = the default of 16
         f.reserve_cus = (phases & FA2_PHASE_LEAVE_ROOM) ? (((phases >> 8) & 0xff) ? ((phases >> 8) & 0xff) : 16) : 0;
-        const FusedWs w = fused_ws((char*)workspace + bwd_base_ws(B, H, q_len), B, H, q_len, head_dim);
+        const FusedWs w = fused_ws((char*)workspace + bwd_base_ws(B, H, q_hs), B, H, q_hs, head_dim);
         return hip_status(fa2::launch_bwd_fused_bf16(f, w.acc, w.ctl, 1, (hipStream_t)stream, w.rcpad));
+    }
+    if (allow_single && bwd_fused_shape(q_hs, head_dim, dtype) &&
+        workspace_bytes >= fa2_backward_workspace_bytes(B, H, q_hs, head_dim, dtype)) {
+        // the two kernels on a workspace that carries a control block: its error word must describe this call (fa2_backward_status)
+        const FusedWs w = fused_ws((char*)workspace + bwd_base_ws(B, H, q_hs), B, H, q_hs, head_dim);
+        const hipError_t e = fa2::bwd_fused_clear_error(w.ctl, (hipStream_t)stream);
+        if (e != hipSuccess) return hip_status(e);
     }
     fa2::BwdArgs a{};
     a.Q = Q; a.K = K; a.V = V; a.O = O; a.dO = dO; a.L = L; a.dQ = dQ; a.dK = dK; a.dV = dV;

@@ -562,14 +562,14 @@ static int ring_backward_impl(fa2_ring_ctx* c,
         if (owner < rank) {           // the owner's first chunk of keys, every local row
             *q0 = 0; *nq = local_seq_len; *nk = half;
             return be.backward_block(be.user, Q_local, Kc, Vc, O_local, L_local, dO_local, tq, tk(par), tv(par), B, H, local_seq_len,
-                                     half, head_dim, softmax_scale, dtype, 0, local_seq_len, 0, 0, 0, bws, pl.ws_bytes, stream, 6);
+                                     half, head_dim, softmax_scale, dtype, 0, local_seq_len, 0, 0, 0, bws, pl.ws_bytes, stream, both);
         }
         // all of the owner's keys, the rows of the second local chunk
         *q0 = half; *nq = half; *nk = local_seq_len;
         const size_t eo = (size_t)half * head_dim;
         return be.backward_block(be.user, (const char*)Q_local + eo * 2, Kc, Vc, (const char*)O_local + eo * 2, L_local + half,
                                  (const char*)dO_local + eo * 2, (char*)tq + eo * 2, tk(par), tv(par), B, H, half, local_seq_len,
-                                 head_dim, softmax_scale, dtype, local_seq_len, 0, half, 0, 0, bws, pl.ws_bytes, stream, 6);
+                                 head_dim, softmax_scale, dtype, local_seq_len, 0, half, 0, 0, bws, pl.ws_bytes, stream, both);
     };
     // acc (+)= the first `nrows` rows of every head of a bf16 piece, starting at row r0
     auto add_rows = [&](float* acc, const void* src, int r0, int nrows, int init) -> int {

@@ -185,7 +185,10 @@ int fa2_backward_phases(const void* Q, const void* K, const void* V, const void*
  * fa2_backward does: a DENSE SQUARE block (q_len = kv_len, dense strides, q_row0 = 0, no shift) of head_dim 128 and a
  * length that is a multiple of 256 runs the single five-product kernel -- provided the workspace is
  * fa2_backward_workspace_bytes(B, H, q_len, ...) (room for its running sums) and the device is the validated layout
- * (fa2_backward_plan) -- every other block the dQ and dK/dV kernels.  A single bit (2 or 4) always runs that kernel.
+ * (fa2_backward_plan) -- and so does an UNMASKED rectangular, head-strided block of head_dim 128 with q_len a multiple of 32
+ * (at least 512) and kv_len a multiple of 256 (at most q_head_stride rounded up to 256), given the workspace of
+ * fa2_backward_workspace_bytes(B, H, q_head_stride, ...): the zig-zag causal ring's half blocks.  Every other block runs the dQ
+ * and dK/dV kernels.  A single bit (2 or 4) always runs that kernel.
  * FA2_PHASE_LEAVE_ROOM (bit 4) asks the single kernel to leave some of the device's CUs free: its persistent workgroups fill a
  * CU's register file for the whole launch, so a kernel on another stream that must run CONCURRENTLY (the ring backward's RCCL
  * exchange of the previous step's dK / dV pieces) would otherwise wait for the launch to end.  How many: bits 8..15 of

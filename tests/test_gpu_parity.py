@@ -479,6 +479,9 @@ def _np_block_backward(Q, K, V, O, L, dO, scale, causal, shift):
     (64, 130, 300, 70, 200, 300, True, 100),      # causal with a positive shift, strided rows
     (128, 512, 512, 0, 512, 512, False, 0),       # dense square, d = 128, length % 256 == 0: the block the SINGLE five-product
     (128, 768, 768, 0, 768, 768, True, 0),        # kernel takes (phases 7), with L shifted as if other key blocks existed
+    (128, 1024, 512, 0, 1024, 1024, False, 0),    # round 4: UNMASKED aligned rectangles run the single kernel too -- every local row
+    (128, 512, 1024, 512, 1024, 1024, False, 0),  # against the owner's first half (k_hs > nk); the second half of the rows against all keys
+    (128, 768, 256, 128, 1024, 512, False, 0),    # and a general one: row offset, both strides larger than the lengths
 ])
 def test_backward_block_rectangular(d, nq, nk, q_row0, q_hs, k_hs, causal, shift):
     """fa2_backward_block: q_len != kv_len, head strides, a row offset into the workspace planes and a causal shift --
@@ -516,6 +519,14 @@ def test_backward_block_rectangular(d, nq, nk, q_row0, q_hs, k_hs, causal, shift
                                 ws.data_ptr(), need, torch.cuda.current_stream().cuda_stream, 7)
     assert st == 0
     torch.cuda.synchronize()
+    if d == 128 and not causal and nq % 32 == 0 and nq >= 512 and nk % 256 == 0:
+        # the single five-product kernel ran: its unit queues were drawn from (the two kernels leave the 0xFF fill there)
+        al = lambda x: (x + 255) & ~255
+        npad = (q_hs + 255) // 256 * 256
+        ctl = ws[3 * al(B * H * q_hs * 4) + al(B * H * npad * d * 4):].view(torch.int32)[:32 * 16].cpu()
+        tickets = ctl[::32]
+        assert int((tickets > 0).sum()) >= 1 and int(tickets[tickets > 0].sum()) >= B * H * (nk // 256), tickets
+        assert lib.fa2_backward_status(ws.data_ptr(), need, B, H, q_hs, d, 0, torch.cuda.current_stream().cuda_stream) == 0
     for h in range(H):
         sl = slice(q_row0, q_row0 + nq)
         rq, rk, rv = _np_block_backward(f32(Qf[0, h, sl]), f32(Kf[0, h, :nk]), f32(Vf[0, h, :nk]), f32(Of[0, h, sl]),

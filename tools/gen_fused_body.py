@@ -71,6 +71,7 @@ GBAR = int(os.environ.get("FA2_GEN_GBAR", "72"))
 # in a phase full of ds_read_b128, 25 - 60 in VALU-only gaps
 DMA_REL = int(os.environ.get("FA2_GEN_DMA_REL", "1"))
 DMA_DL = int(os.environ.get("FA2_GEN_DMA_DL", "12"))
+DMA_POLICY = os.environ.get("FA2_GEN_DMA_POLICY", "")          # experiment: " nt" on the Q / dO tiles' LDS-DMA
 
 
 def vf(kb, s): b = VF + 4 * (kb * KS + s); return f"v[{b}:{b + 3}]"
@@ -302,7 +303,7 @@ def build(chain=False, masked=False):
                 rs = "%[grs]" if which else "%[qrs]"
                 mid = f"s_add_u32 s12, %[qso], {4096 * i}" if i else "s_nop 0"
                 tasks.append(Task(f"s_add_u32 m0, %[mw], @NB+{8192 * which + 4096 * i}\n\t{mid}\n\t"
-                                  f"buffer_load_dwordx4 %[dvo], {rs}, {'s12' if i else '%[qso]'} offen lds", COST["vmem"] + 2, DMA_REL, DMA_DL, "vmem",
+                                  f"buffer_load_dwordx4 %[dvo], {rs}, {'s12' if i else '%[qso]'} offen{DMA_POLICY} lds", COST["vmem"] + 2, DMA_REL, DMA_DL, "vmem",
                                   ("dma", which, i)))
         tasks.append(Task(f"s_cmp_lt_u32 %[wv], 2\n\ts_cbranch_scc0 4f\n\ts_mov_b64 exec, 0xffffffff\n\ts_add_u32 m0, %[mw2], @NB+{2 * 32 * ROWB}\n\t"
                           "s_nop 0\n\tbuffer_load_dword %[rcvo], %[rcrs], %[rcso] offen lds\n\ts_mov_b64 exec, -1\n\t4:", COST["vmem"] + 6, DMA_REL, DMA_DL,
