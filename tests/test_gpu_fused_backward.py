@@ -244,6 +244,8 @@ def test_bench_shape_matches_the_two_kernel_form():
     (2, 8, 1024),
     (1, 3, 768),       # unit lengths 8, 16, 24 sub-tiles: masked region not aligned to the six-body loop
     (1, 9, 2048),
+    (1, 17, 1024),     # 17 heads: the queues take their units in groups of two heads (round 4), and one group has a single head
+    (2, 16, 768),      # 32 heads: two full groups per queue
     (1, 2, 16384),     # 64 key blocks per head
 ])
 def test_causal_fused_backward(B, H, N):
@@ -318,6 +320,39 @@ def test_any_number_of_resident_workgroups(causal):
             hl.fa2_test_set_fused_hooks(0, wgs)
             got = run(hl)
             assert hl.fa2_test_last_fused_grid() == wgs          # the test build's own launcher and kernels ran, at this grid
+            for a, b in zip(got, ref):
+                assert torch.equal(a, b), wgs
+    finally:
+        hl.fa2_test_set_fused_hooks(0, 0)
+
+
+def test_causal_unit_groups_with_few_workgroups():
+    """Round 4's causal unit order: a queue takes its units in groups of two heads, key-block-major inside a group; heads go to
+    a queue's chains in chain order; a ticket whose chain got no head (the odd head's partner in the last group) is skipped and
+    the first chain of a group without a head ends the queue.  17 heads x 4 key blocks with the grid forced down to 1, 2, 5
+    and 11 workgroups (test build): few queues then take MANY groups each, the partial group lands in a different place every
+    time, and the bits must equal the full grid's -- which test_causal_fused_backward checks against the oracle."""
+    fa = _fa()
+    hl = hooks_lib()
+    B, H, N, d = 1, 17, 1024, 128
+    host, dev, O, L, scale = case(B, H, N, seed=53)
+    O, L = fa.flash_attention_2_forward(dev[0], dev[1], dev[2], scale, causal=True)
+    ws = torch.empty(fa._capi.lib().fa2_backward_workspace_bytes(B, H, N, d, 0), dtype=torch.uint8, device="cuda")
+
+    def run(lib):
+        out = [torch.full_like(dev[0], float("nan")) for _ in range(3)]
+        backward_via(lib, dev[0], dev[1], dev[2], O, L, dev[3], scale, True, ws, out)
+        torch.cuda.synchronize()
+        assert lib.fa2_backward_status(P(ws), ws.numel(), B, H, N, d, 0, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+        return out
+
+    ref = run(fa._capi.lib())
+    assert all(bool(torch.isfinite(t.float()).all()) for t in ref)
+    try:
+        for wgs in (1, 2, 5, 11):
+            hl.fa2_test_set_fused_hooks(0, wgs)
+            got = run(hl)
+            assert hl.fa2_test_last_fused_grid() == wgs
             for a, b in zip(got, ref):
                 assert torch.equal(a, b), wgs
     finally:
