@@ -22,14 +22,15 @@ for i in range(cases):
     g = torch.Generator().manual_seed(9000 + i)
     Q = ((torch.rand(B, H, N, d, generator=g) - 0.5) * amp).to(dt)
     K = ((torch.rand(B, H, N, d, generator=g) - 0.5) * amp).to(dt).float()
-    V = (torch.rand(B, H, N, d, generator=g) - 0.5).to(dt)
+    vamp = 1.0 if kind == "fp8" else float(rng.choice([1.0, 4.0, 12.0]))      # |V| up to 6: P V near the top of fp32 when a reference lags
+    V = ((torch.rand(B, H, N, d, generator=g) - 0.5) * vamp).to(dt)
     s = 1.0 / d ** 0.5
     spikes = []
     for _ in range(int(rng.integers(0, 4))):
         h, key = int(rng.integers(0, H)), int(rng.integers(0, N))
         row = int(rng.integers(key, N)) if causal else int(rng.integers(0, N))
         q = Q.float()[0, h, row]
-        mag = float(rng.choice([5.0, 20.0, 45.0, 90.0, 150.0]))
+        mag = float(rng.choice([5.0, 20.0, 45.0, 60.0, 80.0, 86.0, 88.0, 90.0, 150.0]))
         kv = q * (mag / (s * float(q @ q)))
         if kind == "fp8" and float(kv.abs().max()) > 400.0:
             continue
