@@ -234,7 +234,21 @@ __global__ void __launch_bounds__(64 * kF8Waves, 1) __attribute__((amdgpu_num_vg
     const int nrb = (N + kF8Rows - 1) / kF8Rows;
     int head, rb;
     map_block(blockIdx.x, p.BH, nrb, head, rb);
-    if (CAUSAL) rb = nrb - 1 - rb;            // heaviest row blocks first
+    if (CAUSAL) {
+        rb = nrb - 1 - rb;                    // heaviest row blocks first
+        // Round 4: ... over TWO heads of an XCD at a time (row-block-major inside the pair), not head after head: with one head
+        // after the other an XCD's last head still began with its heaviest blocks (a quarter of a CU's whole share each at
+        // BASELINE configs[4]) when the CUs were about to run dry; longest-first over the pair ends with the lightest blocks of
+        // both.  (This kernel has 32 compiler registers and none to spare for the bf16 forward's two-blocks-per-workgroup loop.)
+        if ((p.BH & 7) == 0) {
+            const int x = blockIdx.x & 7, j = blockIdx.x >> 3, hx = p.BH >> 3;
+            const int g = j / (2 * nrb);                       // pair of heads of this XCD
+            const bool full = 2 * g + 1 < hx;                  // (an odd head count per XCD: the last one goes alone)
+            const int r = j - g * 2 * nrb;
+            rb = nrb - 1 - (full ? r >> 1 : r);
+            head = (2 * g + (full ? (r & 1) : 0)) * 8 + x;
+        }
+    }
 
     const char* Qh = (const char*)p.Q + (size_t)head * N * ROWB;
     const char* Kh = (const char*)p.K + (size_t)head * N * ROWB;
