@@ -57,6 +57,36 @@ struct FusedStep {
     uint32_t dso, lso, qso, rcso, pvo, mso;
     int need, pval;
 };
+// head_dim 64 (round 4): the same bodies generated for KS = 4, DT = 2 (FA2_FUSED64_*): four row-read and four transposed-read
+// addresses instead of eight
+#define FA2_FUSED_OPS64 [r0] "v"(roff[0]), [r1] "v"(roff[1]), [r2] "v"(roff[2]), [r3] "v"(roff[3]), [t0] "v"(toff[0]), [t1] "v"(toff[1]),    \
+    [t2] "v"(toff[2]), [t3] "v"(toff[3]), [rc] "v"(rcv), [c2] "s"(c2)
+template <int BUF, int PAR, int VMW, bool MASKED>
+__device__ __forceinline__ void fused_cbody(const uint32_t (&roff)[4], const uint32_t (&toff)[4], uint32_t rcv, float c2, uint32_t dqv,
+                                            uint32_t dvo, uint32_t rcvo, uint32_t mw, uint32_t mw2, int wv, const FusedStep& f, int& err,
+                                            int lo0 = 0, int lo1 = 0)
+{
+#define FA2_FUSED_CASE(B, P)                                                                                                          \
+    if constexpr (BUF == B && PAR == P && MASKED)                                                                                     \
+        asm volatile(FA2_FUSED64_MBODY_B##B##_P##P                                                                                    \
+                     : [err] "+s"(err)                                                                                                \
+                     : FA2_FUSED_OPS64, [vm] "i"(VMW), [dqv] "v"(dqv), [drs] "s"(f.drs), [dso] "s"(f.dso), [lrs] "s"(f.lrs), [lso] "s"(f.lso), \
+                       [mw] "s"(mw), [mw2] "s"(mw2), [qrs] "s"(f.qrs), [grs] "s"(f.grs), [rcrs] "s"(f.rcrs), [qso] "s"(f.qso),           \
+                       [rcso] "s"(f.rcso), [dvo] "v"(dvo), [rcvo] "v"(rcvo), [wv] "s"(wv), [ctl] "s"(f.ctl), [pvo] "s"(f.pvo),           \
+                       [mso] "s"(f.mso), [need] "s"(f.need), [pval] "s"(f.pval), [lo0] "v"(lo0), [lo1] "v"(lo1)                        \
+                     : FA2_FUSED_CLOBBERS, "s12", "s13", "scc", "exec", "m0", "v39");                                                 \
+    if constexpr (BUF == B && PAR == P && !MASKED)                                                                                    \
+        asm volatile(FA2_FUSED64_CBODY_B##B##_P##P                                                                                    \
+                     : [err] "+s"(err)                                                                                                \
+                     : FA2_FUSED_OPS64, [vm] "i"(VMW), [dqv] "v"(dqv), [drs] "s"(f.drs), [dso] "s"(f.dso), [lrs] "s"(f.lrs), [lso] "s"(f.lso), \
+                       [mw] "s"(mw), [mw2] "s"(mw2), [qrs] "s"(f.qrs), [grs] "s"(f.grs), [rcrs] "s"(f.rcrs), [qso] "s"(f.qso),           \
+                       [rcso] "s"(f.rcso), [dvo] "v"(dvo), [rcvo] "v"(rcvo), [wv] "s"(wv), [ctl] "s"(f.ctl), [pvo] "s"(f.pvo),           \
+                       [mso] "s"(f.mso), [need] "s"(f.need), [pval] "s"(f.pval)                                                        \
+                     : FA2_FUSED_CLOBBERS, "s12", "s13", "scc", "exec", "m0", "v39");
+    FA2_FUSED_CASE(0, 0) FA2_FUSED_CASE(0, 1) FA2_FUSED_CASE(1, 0) FA2_FUSED_CASE(1, 1) FA2_FUSED_CASE(2, 0) FA2_FUSED_CASE(2, 1)
+#undef FA2_FUSED_CASE
+}
+
 template <int BUF, int PAR, int VMW, bool MASKED>
 __device__ __forceinline__ void fused_cbody(const uint32_t (&roff)[8], const uint32_t (&toff)[8], uint32_t rcv, float c2, uint32_t dqv,
                                             uint32_t dvo, uint32_t rcvo, uint32_t mw, uint32_t mw2, int wv, const FusedStep& f, int& err,
@@ -241,22 +271,32 @@ __device__ __forceinline__ bool fused_spin_over(int* ctl, int spins)
 // head, heads q_hs rows apart, the first of them row q_row0 of the dense row-constant planes, against Nk keys (a multiple of
 // 256), heads k_hs rows apart: the unmasked half blocks of the zig-zag causal ring's backward.  Its own instantiation too: the
 // square kernels keep one length in one register.
-template <bool CHAIN, bool CAUSAL, bool RAGGED = false, bool RECT = false>
+// HD = 64 (chained, aligned, square; round 4): the bodies generated for head_dim 64 (40 MFMAs per sub-tile).  The dQ tile of a
+// sub-tile is 32 x 64: wave w forms columns 32 (w & 1) .. + 31 over the 128 keys of half w >> 1 of the workgroup's 256, so a
+// sub-tile has TWO running sums per column block (one per key half), each handed from key block to key block exactly like the one
+// of head_dim 128 -- the layout of dQacc ([tile][wave][g][lane] x 4 floats) and the bodies' eight loads / stores are the same --
+// and fa2_bwd_fused_dq_out_chain64_kernel adds the two.
+template <bool CHAIN, bool CAUSAL, bool RAGGED = false, bool RECT = false, int HD = 128>
 __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) fa2_bwd_fused_kernel(FusedArgs fp)
 {
     static_assert(CHAIN || !RAGGED, "the atomics form has no ragged variant");
     static_assert(!RECT || (CHAIN && !CAUSAL && !RAGGED), "rectangular blocks: chained, unmasked, aligned");
+    static_assert(HD == 128 || (HD == 64 && CHAIN && !RAGGED && !RECT), "head_dim 64: chained, aligned, square");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const BwdArgs& p = fp.b;
-    constexpr int D = 128, ROWB = 256, KS = 8, DT = 4;
+    constexpr int D = HD, ROWB = 2 * D, KS = D / 16, DT = D / 32;
+    constexpr int DQW = 128;                         // floats per row of the running-sum layout: 4 waves x 32 columns, either head_dim
     constexpr int TROWS = 32;
-    constexpr int QRING = FA2_FUSED_QRING, BUFB = FA2_FUSED_BUFB, DSB = FA2_FUSED_DSB;
-    constexpr int CPR = 16, RPI = 4, NINS = TROWS / RPI;      // 8 one-KiB DMA pieces per tensor per 32-row tile
-    constexpr int VF = FA2_FUSED_VF, DQT = FA2_FUSED_DQT, ROFFK = FA2_FUSED_ROFFK, DSWR = FA2_FUSED_DSWR, DSRD = FA2_FUSED_DSRD,
-                  KT = FA2_FUSED_KT;
-    constexpr int VMW = CHAIN ? 4 : 63;              // vector-memory operations issued behind the DQT loads and in front of the E chain: >= 4 DMA pieces
-    int* const mail = reinterpret_cast<int*>(smem + FA2_FUSED_LDS);      // 16 bytes behind the generated map: the unit taken
-    const uint32_t mail_addr = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem) + FA2_FUSED_LDS;
+    constexpr bool W = D == 128;
+    constexpr int QRING = W ? FA2_FUSED_QRING : FA2_FUSED64_QRING, BUFB = W ? FA2_FUSED_BUFB : FA2_FUSED64_BUFB,
+                  DSB = W ? FA2_FUSED_DSB : FA2_FUSED64_DSB, LDSB = W ? FA2_FUSED_LDS : FA2_FUSED64_LDS;
+    constexpr int CPR = D / 8, RPI = 64 / CPR, NINS = TROWS / RPI;      // one-KiB DMA pieces per tensor per 32-row tile: 8 (4 at head_dim 64)
+    constexpr int VF = W ? FA2_FUSED_VF : FA2_FUSED64_VF, DQT = W ? FA2_FUSED_DQT : FA2_FUSED64_DQT,
+                  ROFFK = W ? FA2_FUSED_ROFFK : FA2_FUSED64_ROFFK, DSWR = W ? FA2_FUSED_DSWR : FA2_FUSED64_DSWR,
+                  DSRD = W ? FA2_FUSED_DSRD : FA2_FUSED64_DSRD, KT = W ? FA2_FUSED_KT : FA2_FUSED64_KT;
+    constexpr int VMW = CHAIN ? (W ? 4 : 2) : 63;    // vector-memory operations issued behind the DQT loads and in front of the E chain: the wave's DMA pieces
+    int* const mail = reinterpret_cast<int*>(smem + LDSB);      // 16 bytes behind the generated map: the unit taken
+    const uint32_t mail_addr = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem) + LDSB;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -291,11 +331,14 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
         constexpr int sidx = decltype(S)::value;
         fused_vset<ROFFK + sidx>(lbase + lds_off<D>(ki + 64 * wave, 2 * sidx + h));
     });
+    // E: this wave's 32 columns of dQ over "its" keys -- head_dim 128: column block = wave, all 256 keys; head_dim 64: column
+    // block wave & 1, the 128 keys of half wave >> 1 (the bodies step 16 keys per immediate from these bases)
+    const int ecol = W ? wave : (wave & 1), ekey0 = W ? 0 : 128 * (wave >> 1);
     static_for<2>([&](auto JJ) {                   // K^T for this wave's 32 columns; dS^T of the workgroup's tile
         constexpr int jj = decltype(JJ)::value;
-        fused_vset<KT + jj>(lbase + lds_off<D>(8 * jj + 4 * h + trq, 4 * wave + 2 * trcb + (trp >> 1)) + 8 * (trp & 1));
+        fused_vset<KT + jj>(lbase + ekey0 * ROWB + lds_off<D>(8 * jj + 4 * h + trq, 4 * ecol + 2 * trcb + (trp >> 1)) + 8 * (trp & 1));
         const int row = 8 * jj + 4 * h + trq;
-        fused_vset<DSRD + jj>(lbase + DSB + row * 64 + 8 * ((4 * trcb + trp) ^ FA2_FUSED_DSKEY(row)));
+        fused_vset<DSRD + jj>(lbase + DSB + (ekey0 + row) * 64 + 8 * ((4 * trcb + trp) ^ FA2_FUSED_DSKEY(row)));
     });
     static_for<4>([&](auto C) {                    // dS write addresses: 8-byte chunk (4 sp + 2 jp + h) of row 64 w + ki
         constexpr int c = decltype(C)::value;
@@ -424,7 +467,7 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
         // dK^T, dV^T <- 0: sixteen MFMAs on a zero fragment instead of 256 accumulator writes
         {
             const u32x4 z = {0u, 0u, 0u, 0u};
-            static_for<16>([&](auto T) { fused_acc_zero<decltype(T)::value>(z); });
+            static_for<4 * DT>([&](auto T) { fused_acc_zero<decltype(T)::value>(z); });
         }
 
         // ---- LDS-DMA staging of a 32-row Q / dO tile + its row constants into ring slot `buf`
@@ -460,9 +503,10 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
         fused_dq_zero<DQT>();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                 // V fragments, K image and the first tile have landed
-        asm volatile(FA2_FUSED_PRO : : FA2_FUSED_OPS, [vm] "i"(VMW) : FA2_FUSED_CLOBBERS);
+        if constexpr (W) asm volatile(FA2_FUSED_PRO : : FA2_FUSED_OPS, [vm] "i"(VMW) : FA2_FUSED_CLOBBERS);
+        else asm volatile(FA2_FUSED64_PRO : : FA2_FUSED_OPS64, [vm] "i"(VMW) : FA2_FUSED_CLOBBERS);
 
-        const auto dq_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(fp.dQacc + (size_t)head * NPQ * D), 0, NPQ * D * 4, 0x00020000);
+        const auto dq_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(fp.dQacc + (size_t)head * NPQ * DQW), 0, NPQ * DQW * 4, 0x00020000);
         int* const mine = prog_base + head * ncb + cb;
         const int* const prev = mine - 1;                             // the key block this one takes the running sums from
         const int prev_off = (int)((prev - fp.ctl) * 4);
@@ -488,8 +532,8 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
                 FusedStep f;
                 f.drs = dq_rsrc;
                 f.lrs = lrs_unit;
-                f.dso = (uint32_t)(tl(t - 1) * TROWS * D * 4);
-                f.lso = (uint32_t)(tl(t) * TROWS * D * 4);
+                f.dso = (uint32_t)(tl(t - 1) * TROWS * DQW * 4);
+                f.lso = (uint32_t)(tl(t) * TROWS * DQW * 4);
                 f.qrs = q_rsrc; f.grs = g_rsrc; f.rcrs = rc_rsrc; f.ctl = ctl_rsrc;
                 f.qso = (uint32_t)(tl(t + 1) * TROWS * ROWB + wave * 1024);
                 f.rcso = (uint32_t)(tl(t + 1) * TROWS * 4);
@@ -511,8 +555,8 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
                 const bool has_prev = t < n_u && cb > 0;
                 f.drs = live ? dq_rsrc : null_rsrc;
                 f.lrs = has_prev && !(FA2_FUSED_DIAG & 2) ? dq_rsrc : null_rsrc;
-                f.dso = (uint32_t)__builtin_amdgcn_readfirstlane(tl(t - 1) * TROWS * D * 4);
-                f.lso = (uint32_t)__builtin_amdgcn_readfirstlane(tl(t) * TROWS * D * 4);
+                f.dso = (uint32_t)__builtin_amdgcn_readfirstlane(tl(t - 1) * TROWS * DQW * 4);
+                f.lso = (uint32_t)__builtin_amdgcn_readfirstlane(tl(t) * TROWS * DQW * 4);
                 f.qrs = q_rsrc; f.grs = g_rsrc; f.rcrs = rc_rsrc; f.ctl = ctl_rsrc;
                 f.qso = more ? (uint32_t)(tl(t + 1) * TROWS * ROWB + wave * 1024) : 0x40000000u;      // out of range: zeros
                 f.rcso = more ? (uint32_t)(tl(t + 1) * TROWS * 4) : 0x40000000u;
@@ -542,8 +586,9 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
                 st_cycles += (int)(__builtin_readcyclecounter() - b0);       // cycles inside the bodies (reported as "waited")
 #endif
             } else {
+                static_assert(W || CHAIN, "head_dim 64: chained form only");
                 stage(t + 1, (buf + 1) % 3);
-                fused_body<buf, par, VMW>(roff, toff, rcv, c2);
+                if constexpr (W) fused_body<buf, par, VMW>(roff, toff, rcv, c2);
 #ifndef FA2_FUSED_NO_DQ                              // diagnostic build: how long the kernel takes without the dQ traffic
                 // the body's E stage has finished the dQ tile of sub-tile t - 1
                 if (t >= 1 && t <= ntiles) fused_dq_atomic<DQT>(dq_rsrc, dqv, (uint32_t)__builtin_amdgcn_readfirstlane((t - 1) * TROWS * D * 4));
@@ -604,7 +649,7 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
             char* dVk = dVb + koff;
             static_for<2 * DT>([&](auto G) {
                 constexpr int dt = decltype(G)::value / 2, gp = decltype(G)::value % 2;
-                constexpr int RK = 16 * (kb * DT + dt) + 8 * gp, RV = 128 + RK;
+                constexpr int RK = 16 * (kb * DT + dt) + 8 * gp, RV = 32 * DT + RK;
                 auto pack4 = [&](float a, float b, float c, float d, float sc) {
                     bf16x4 v;
                     v[0] = (__bf16)(a * sc); v[1] = (__bf16)(b * sc); v[2] = (__bf16)(c * sc); v[3] = (__bf16)(d * sc);
@@ -678,6 +723,27 @@ __global__ void __launch_bounds__(256) fa2_bwd_fused_dq_out_chain_kernel(const f
     }
 }
 
+// head_dim 64: slot (tile, wave, g, lane) holds rows 32 tile + 8 g + 4 (lane >> 5) + (0 .. 3) of column 32 (wave & 1) + (lane & 31),
+// summed over the keys of half wave >> 1 of every key block: dQ = scale x (the sum of half 0 + the sum of half 1).  n4h = BH x
+// (N / 32) x 2 column blocks x 4 x 64 threads' worth.
+__global__ void __launch_bounds__(256) fa2_bwd_fused_dq_out_chain64_kernel(const float* __restrict__ acc, __bf16* __restrict__ dQ, size_t n4h, float scale,
+                                                                            const int* __restrict__ err, int N)
+{
+    const float poison = *err ? __builtin_nanf("") : 0.0f;
+    const size_t stride = (size_t)gridDim.x * 256;
+    const size_t tiles = (size_t)(N / 32);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4h; i += stride) {
+        const int lane = (int)(i & 63), g = (int)((i >> 6) & 3), cbk = (int)((i >> 8) & 1);
+        const size_t tg = i >> 9, head = tg / tiles;
+        const size_t slot = ((tg * 4 + cbk) * 4 + g) * 64 + lane;
+        const f32x4 a = reinterpret_cast<const f32x4*>(acc)[slot], b = reinterpret_cast<const f32x4*>(acc)[slot + 2 * 4 * 64];
+        const int row = (int)(tg % tiles) * 32 + 8 * g + 4 * (lane >> 5);
+        __bf16* o = dQ + (head * (size_t)N + row) * 64 + 32 * cbk + (lane & 31);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[(size_t)e * 64] = (__bf16)((a[e] + b[e]) * scale + poison);
+    }
+}
+
 // ragged launches: the row-constant planes [2][BH][N] copied to [2][BH][NP] with (-1e30, 0) in the rows past the end -- a row
 // that does not exist then has S' = -1e30, P = exp2(-huge) = 0 and dS = 0 whatever the (zero) Q / dO rows give
 __global__ void __launch_bounds__(256) fa2_bwd_fused_rcpad_kernel(const float* __restrict__ rc, float* __restrict__ out, int BH, int N, int NP)
@@ -734,7 +800,8 @@ hipError_t launch_bwd_fused_bf16(const BwdArgs& a, float* dQacc, int* ctl, int m
     // a rectangular and / or head-strided block (fa2_backward_block: the causal ring's unmasked half blocks): chained form,
     // no mask, both lengths aligned; everything else is the dense square problem
     const bool rect = a.Nq != a.Nk || a.q_hs != a.Nq || a.k_hs != a.Nk || a.q_row0 != 0;
-    if (a.d != 128 || a.Nk < 1 || a.Nq < 1) return hipErrorInvalidValue;
+    if ((a.d != 128 && a.d != 64) || a.Nk < 1 || a.Nq < 1) return hipErrorInvalidValue;
+    if (a.d == 64 && (mode != 1 || ragged || rect)) return hipErrorInvalidValue;          // head_dim 64: chained, aligned, square
     if (rect && (mode != 1 || a.causal || ragged || a.Nq % 32 != 0 || a.q_row0 < 0 || a.q_hs < a.q_row0 + a.Nq || a.k_hs < a.Nk))
         return hipErrorInvalidValue;
     if (ragged && (mode != 1 || !rcpad)) return hipErrorInvalidValue;
@@ -758,7 +825,7 @@ hipError_t launch_bwd_fused_bf16(const BwdArgs& a, float* dQacc, int* ctl, int m
         if (e != hipSuccess) return e;
     }
     FusedArgs fa{a, dQacc, ctl, npad, ragged ? (const float*)rcpad : (const float*)a.RC, g_hook_fault};
-    constexpr int lds = FA2_FUSED_LDS + 16;
+    const int lds = (a.d == 64 ? FA2_FUSED64_LDS : FA2_FUSED_LDS) + 16;
     if (mode == 0) {
         e = hipMemsetAsync(dQacc, 0, elems * 4, stream);
         if (e != hipSuccess) return e;
@@ -791,8 +858,16 @@ hipError_t launch_bwd_fused_bf16(const BwdArgs& a, float* dQacc, int* ctl, int m
         if (g_hook_grid >= 1 && g_hook_grid < wgs) wgs = g_hook_grid;
         FA2_HOOK_NOTE_GRID(wgs);
         const dim3 grid((unsigned)wgs);
-        static bool set_cr[64] = {}, set_tr[64] = {}, set_re[64] = {};
-        if (rect) {
+        static bool set_cr[64] = {}, set_tr[64] = {}, set_re[64] = {}, set_64[64] = {}, set_64c[64] = {};
+        if (a.d == 64 && a.causal) {
+            e = ensure_dynamic_lds(fa2_bwd_fused_kernel<true, true, false, false, 64>, lds, set_64c);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((fa2_bwd_fused_kernel<true, true, false, false, 64>), grid, dim3(256), lds, stream, fa);
+        } else if (a.d == 64) {
+            e = ensure_dynamic_lds(fa2_bwd_fused_kernel<true, false, false, false, 64>, lds, set_64);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((fa2_bwd_fused_kernel<true, false, false, false, 64>), grid, dim3(256), lds, stream, fa);
+        } else if (rect) {
             e = ensure_dynamic_lds(fa2_bwd_fused_kernel<true, false, false, true>, lds, set_re);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL((fa2_bwd_fused_kernel<true, false, false, true>), grid, dim3(256), lds, stream, fa);
@@ -819,6 +894,9 @@ hipError_t launch_bwd_fused_bf16(const BwdArgs& a, float* dQacc, int* ctl, int m
     if (mode == 0)
         hipLaunchKernelGGL(fa2_bwd_fused_dq_out_kernel, dim3(2048), dim3(256), 0, stream, dQacc, (__bf16*)a.dQ, elems / 8, a.scale,
                            (const int*)nullptr);
+    else if (a.d == 64)
+        hipLaunchKernelGGL(fa2_bwd_fused_dq_out_chain64_kernel, dim3(4096), dim3(256), 0, stream, dQacc, (__bf16*)a.dQ, elems / 8, a.scale,
+                           ctl + kCtlError, a.Nk);
     else
         hipLaunchKernelGGL(fa2_bwd_fused_dq_out_chain_kernel, dim3(4096), dim3(256), 0, stream, dQacc, (__bf16*)a.dQ, elems / 4, a.scale,
                            ctl + kCtlError, rect ? a.Nq : a.Nk, rect ? a.Nq : npad, rect ? a.q_hs : a.Nk);

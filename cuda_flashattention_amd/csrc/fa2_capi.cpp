@@ -188,7 +188,10 @@ static size_t bwd_base_ws(int B, int H, int rows) { return 3 * align256((size_t)
 static int fused_npad(int n) { return (n + 255) / 256 * 256; }
 static bool bwd_fused_shape(int seq_len, int head_dim, int dtype)
 {
-    if (dtype != FA2_DTYPE_BF16 || head_dim != 128 || seq_len < 1) return false;
+    if (dtype != FA2_DTYPE_BF16 || seq_len < 1) return false;
+    // head_dim 64 (round 4): the aligned lengths only (multiples of 256; the ragged and rectangular instantiations are head_dim 128's)
+    if (head_dim == 64) return seq_len % 256 == 0 && (long long)seq_len * 128 * 4 <= 0x7fffffffLL;
+    if (head_dim != 128) return false;
     const long long np = fused_npad(seq_len), n64 = (seq_len + 63) / 64 * 64;
     return 5 * np <= 7 * n64 && np * head_dim * 4 <= 0x7fffffffLL;
 }
@@ -197,7 +200,8 @@ struct FusedWs { float* acc; int* ctl; float* rcpad; size_t bytes; };
 static FusedWs fused_ws(void* base, int B, int H, int seq_len, int head_dim)
 {
     const int np = fused_npad(seq_len);
-    const size_t a = align256((size_t)B * H * np * head_dim * 4), c = align256(fa2::bwd_fused_ctl_bytes(B * H, np));
+    (void)head_dim;      // the running sums are [np / 32 sub-tiles][4 waves][32 x 32] fp32 at either head_dim: 128 floats per row
+    const size_t a = align256((size_t)B * H * np * 128 * 4), c = align256(fa2::bwd_fused_ctl_bytes(B * H, np));
     const size_t r = np != seq_len ? align256((size_t)2 * B * H * np * sizeof(float)) : 0;
     char* b = (char*)base;
     return FusedWs{(float*)b, (int*)(b + a), r ? (float*)(b + a + c) : nullptr, a + c + r};
@@ -290,8 +294,9 @@ int fa2_backward_phases(const void* Q, const void* K, const void* V, const void*
 int fa2_backward_plan(int B, int H, int seq_len, int head_dim, int dtype, int causal, const char** reason)
 {
     (void)causal;
-    static const char* const kShape = "two kernels: the single kernel takes bf16, head_dim 128, and a seq_len whose padding to a "
-                                      "multiple of 256 costs less than two block products (5 roundup(N,256) <= 7 roundup(N,64))";
+    static const char* const kShape = "two kernels: the single kernel takes bf16 with head_dim 128 and a seq_len whose padding to a "
+                                      "multiple of 256 costs less than two block products (5 roundup(N,256) <= 7 roundup(N,64)), or "
+                                      "head_dim 64 and a seq_len that is a multiple of 256";
     static const char* const kEnv = "two kernels: FA2_BACKWARD_PATH=two_kernel";
     static const char* const kF32 = "fp32 path (exact f32 MFMA kernels)";
     if (reason) *reason = "";
@@ -414,7 +419,7 @@ int fa2_backward_fused(const void* Q, const void* K, const void* V, const void* 
     if (!st) st = check_bwd_planes(B, H, seq_len);
     if (st) return st;
     if (!bwd_fused_shape(seq_len, head_dim, FA2_DTYPE_BF16) || (mode != 0 && mode != 1)) return FA2_ERR_UNSUPPORTED;
-    if (mode == 0 && seq_len % 256 != 0) return FA2_ERR_UNSUPPORTED;          // the atomics form has no ragged variant
+    if (mode == 0 && (seq_len % 256 != 0 || head_dim != 128)) return FA2_ERR_UNSUPPORTED;      // the atomics form: head_dim 128, aligned
     if (mode == 1 && !fa2::bwd_fused_device_ok(nullptr)) return FA2_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < fa2_backward_fused_workspace_bytes(B, H, seq_len, head_dim)) return FA2_ERR_WORKSPACE;
     fa2::BwdArgs a{};

@@ -118,8 +118,9 @@ int fa2_forward_fp8_scaled(const void* Q, const void* K, const void* V, void* O,
                            void* workspace, size_t workspace_bytes, void* stream);
 
 /* Bytes of scratch fa2_backward needs for this problem: D and the row-constant planes, plus -- for the shapes the
- * single-kernel backward takes (bf16, head_dim 128; see fa2_backward) -- the fp32 running sums of dQ (B H NP head_dim 4 bytes,
- * NP = seq_len rounded up to a multiple of 256), a small control block and, when NP != seq_len, padded row-constant planes. */
+ * single-kernel backward takes (bf16; head_dim 128, or head_dim 64 at aligned lengths: see fa2_backward) -- the fp32 running sums
+ * of dQ (B H NP 128 x 4 bytes at either head_dim, NP = seq_len rounded up to a multiple of 256), a small control block and, when
+ * NP != seq_len, padded row-constant planes. */
 size_t fa2_backward_workspace_bytes(int B, int H, int seq_len, int head_dim, int dtype);
 
 /* dQ, dK, dV from Q, K, V, O, L (forward outputs) and dO.  Deterministic: no floating-point atomics, every
@@ -131,6 +132,8 @@ size_t fa2_backward_workspace_bytes(int B, int H, int seq_len, int head_dim, int
  *     the end masked, rows past the end given row constants that make P vanish, nothing past the end stored); it is taken
  *     whenever that padding costs less than the two extra products of the other form: 5 roundup(N, 256) <= 7 roundup(N, 64),
  *     i.e. every multiple of 256, every N >= 897 and the lengths just below a multiple of 256 under that;
+ *   - bf16, head_dim 64, seq_len a multiple of 256 (causal or not; round 4): the same kernel built for head_dim 64 (a sub-tile's
+ *     dQ tile is summed in two key halves, i.e. two running sums per column block);
  *   - everything else: a dQ kernel and a dK/dV kernel (seven products, csrc/fa2_bwd_bf16.hip).
  * The environment variable FA2_BACKWARD_PATH=two_kernel keeps every shape on the second form.
  * PLACEMENT ASSUMPTION of the first form: its workgroups read HW_REG_XCC_ID and hand running sums to each other through the
@@ -205,7 +208,7 @@ int fa2_backward_block(const void* Q, const void* K, const void* V, const void* 
 /* The single-kernel five-product backward (csrc/fa2_bwd_fused.hip) with the way dQ is summed over the key-block
  * workgroups of a head chosen by the caller -- mode 1: handed from key block to key block in a fixed order by a
  * persistent grid (deterministic; what fa2_backward uses), mode 0: fp32 atomics (NOT bit-reproducible; kept as the
- * measured alternative; seq_len a multiple of 256 only).  bf16, d = 128, non-causal (fa2_backward also takes the causal case), the seq_len rule of fa2_backward;
+ * measured alternative; seq_len a multiple of 256 and d = 128 only).  bf16, d = 128 or (mode 1, aligned lengths) 64, non-causal (fa2_backward also takes the causal case), the seq_len rule of fa2_backward;
  * FA2_ERR_UNSUPPORTED otherwise.  Workspace: fa2_backward_fused_workspace_bytes (= fa2_backward_workspace_bytes). */
 size_t fa2_backward_fused_workspace_bytes(int B, int H, int seq_len, int head_dim);
 int fa2_backward_fused(const void* Q, const void* K, const void* V, const void* O, const float* L,

@@ -61,7 +61,10 @@ def test_argument_checking_status_codes():
     assert lib.fa2_forward(one, one, one, one, one, 1, 1, 128, 64, 0.125, 7, 0, None) == -4
     assert lib.fa2_backward(*([one] * 9), 1, 1, 128, 64, 0.125, 0, 0, None, 0, None) == -5
     base = 3 * 4 * 16 * 8192 * 4                       # D and the two row-constant planes
-    assert lib.fa2_backward_workspace_bytes(4, 16, 8192, 64, 0) == base          # d = 64: the two-kernel form only
+    # d = 64 (round 4): aligned lengths run the single kernel too -- the same running-sum layout (128 floats per row: four waves x
+    # 32 columns, two key halves per column block) and control block as d = 128; other lengths the two kernels
+    assert lib.fa2_backward_workspace_bytes(4, 16, 8192, 64, 0) == lib.fa2_backward_workspace_bytes(4, 16, 8192, 128, 0)
+    assert lib.fa2_backward_workspace_bytes(4, 16, 8200, 64, 0) == 3 * ((4 * 16 * 8200 * 4 + 255) // 256 * 256)
     assert lib.fa2_backward_workspace_bytes(4, 16, 8192, 128, 1) == base         # fp32
     fused = lib.fa2_backward_workspace_bytes(4, 16, 8192, 128, 0)                # + fp32 dQ sums + a control block
     assert base + 4 * 16 * 8192 * 128 * 4 < fused < base + 4 * 16 * 8192 * 128 * 4 + (1 << 20)

@@ -359,6 +359,89 @@ def test_causal_unit_groups_with_few_workgroups():
         hl.fa2_test_set_fused_hooks(0, 0)
 
 
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("B,H,N", [
+    (1, 1, 256),       # one key block: no hand-off
+    (1, 2, 512),
+    (2, 8, 1024),
+    (1, 3, 768),
+    (1, 9, 2048),
+    (1, 17, 1024),     # causal: a partial group of heads in one queue
+    (1, 2, 16384),     # 64 key blocks per head
+])
+def test_fused_backward_head_dim_64(B, H, N, causal):
+    """Round 4: head_dim 64 at aligned lengths runs the single five-product kernel too (its own generated bodies: 40 MFMAs per
+    sub-tile; the dQ tile's two key halves are two running sums, added by the output pass).  Through fa2_backward, which must
+    say so (fa2_backward_plan = 1): against the oracle (whole tensors up to N = 2048, one whole head at N = 16384), bit-
+    reproducible with a dirty workspace, and within bf16 rounding of the two-kernel form."""
+    import oracle
+    fa = _fa()
+    lib = fa._capi.lib()
+    d = 64
+    why = ctypes.c_char_p()
+    assert lib.fa2_backward_plan(B, H, N, d, 0, 1 if causal else 0, ctypes.byref(why)) == 1, why.value
+    g = torch.Generator(device="cuda").manual_seed(64 * N + H)
+    dev = [((torch.rand(B, H, N, d, device="cuda", generator=g) - 0.5) * (0.4 if i == 3 else 1.0)).bfloat16() for i in range(4)]
+    scale = d ** -0.5
+    O, L = fa.flash_attention_2_forward(dev[0], dev[1], dev[2], scale, causal=causal)
+    ws = torch.empty(lib.fa2_backward_workspace_bytes(B, H, N, d, 0), dtype=torch.uint8, device="cuda")
+    a = [torch.full_like(dev[0], float("nan")) for _ in range(3)]
+    b = [torch.full_like(dev[0], float("nan")) for _ in range(3)]
+    c = [torch.empty_like(dev[0]) for _ in range(3)]
+    fa.flash_attention_2_backward(dev[0], dev[1], dev[2], O, L, dev[3], scale, causal=causal, dQ=a[0], dK=a[1], dV=a[2], workspace=ws)
+    ws.fill_(0xa5)
+    fa.flash_attention_2_backward(dev[0], dev[1], dev[2], O, L, dev[3], scale, causal=causal, dQ=b[0], dK=b[1], dV=b[2], workspace=ws)
+    assert lib.fa2_backward_status(P(ws), ws.numel(), B, H, N, d, 0, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    for ph in (1, 6):
+        fa.flash_attention_2_backward(dev[0], dev[1], dev[2], O, L, dev[3], scale, causal=causal, dQ=c[0], dK=c[1], dV=c[2], workspace=ws,
+                                      phases=ph)
+    torch.cuda.synchronize()
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    for name, x, y in zip(("dQ", "dK", "dV"), a, c):
+        assert np.isfinite(f32(x)).all(), name
+        assert rel(f32(x), f32(y).astype(np.float64)) <= 1.5e-3, (name, rel(f32(x), f32(y).astype(np.float64)))
+    if N <= 2048:
+        want = oracle.attention_backward(*[f32(t) for t in dev], scale, causal=causal)
+        for name, x, w in zip(("dQ", "dK", "dV"), a, want):
+            assert rel(f32(x), w) <= BF16_REL, (name, rel(f32(x), w))
+    else:
+        h = H - 1
+        want = oracle.attention_backward_head(*[f32(t[0, h]) for t in dev], scale, causal=causal)
+        for name, x, w in zip(("dQ", "dK", "dV"), a, want):
+            assert rel(f32(x[0, h]), w) <= BF16_REL, (name, rel(f32(x[0, h]), w))
+
+
+def test_head_dim_64_with_few_workgroups():
+    """The head_dim-64 kernel's hand-off under forced grids of 1, 3 and 11 workgroups (test build): same bits as the full grid."""
+    fa = _fa()
+    hl = hooks_lib()
+    B, H, N, d = 1, 5, 1024, 64
+    g = torch.Generator(device="cuda").manual_seed(6464)
+    dev = [((torch.rand(B, H, N, d, device="cuda", generator=g) - 0.5) * (0.4 if i == 3 else 1.0)).bfloat16() for i in range(4)]
+    scale = d ** -0.5
+    ws = torch.empty(fa._capi.lib().fa2_backward_workspace_bytes(B, H, N, d, 0), dtype=torch.uint8, device="cuda")
+    for causal in (False, True):
+        O, L = fa.flash_attention_2_forward(dev[0], dev[1], dev[2], scale, causal=causal)
+
+        def run(lib):
+            out = [torch.full_like(dev[0], float("nan")) for _ in range(3)]
+            backward_via(lib, dev[0], dev[1], dev[2], O, L, dev[3], scale, causal, ws, out)
+            torch.cuda.synchronize()
+            return out
+        ref = run(fa._capi.lib())
+        assert all(bool(torch.isfinite(t.float()).all()) for t in ref)
+        try:
+            for wgs in (1, 3, 11):
+                hl.fa2_test_set_fused_hooks(0, wgs)
+                got = run(hl)
+                assert hl.fa2_test_last_fused_grid() == wgs
+                for x, y in zip(got, ref):
+                    assert torch.equal(x, y), (causal, wgs)
+        finally:
+            hl.fa2_test_set_fused_hooks(0, 0)
+
+
 def test_two_launches_on_two_streams_share_the_gpu():
     """Two persistent grids in flight at once (separate workspaces, separate streams), each wanting every CU: whatever the
     dispatcher gives each of them, both must finish and produce the bits of a launch that had the GPU to itself."""
@@ -471,7 +554,8 @@ def test_backward_plan_names_the_implementation():
     lib = _fa()._capi.lib()
     why = ctypes.c_char_p()
     assert lib.fa2_backward_plan(4, 16, 8192, 128, 0, 0, ctypes.byref(why)) == 1 and b"single" in why.value
-    assert lib.fa2_backward_plan(4, 16, 8192, 64, 0, 0, ctypes.byref(why)) == 2 and b"two kernels" in why.value
+    assert lib.fa2_backward_plan(4, 16, 8192, 64, 0, 0, ctypes.byref(why)) == 1 and b"single" in why.value      # round 4: head_dim 64, aligned
+    assert lib.fa2_backward_plan(4, 16, 8200, 64, 0, 0, ctypes.byref(why)) == 2 and b"two kernels" in why.value and b"head_dim 64" in why.value
     assert lib.fa2_backward_plan(1, 1, 300, 128, 0, 0, ctypes.byref(why)) == 2
     assert lib.fa2_backward_plan(1, 1, 256, 128, 1, 0, ctypes.byref(why)) == 2 and b"fp32" in why.value
     assert lib.fa2_backward_plan(1, 1, 256, 128, 2, 0, None) < 0
@@ -485,16 +569,19 @@ def test_status_codes():
     call = lambda N, d, mode, nb: lib.fa2_backward_fused(P(x), P(x), P(x), P(x), P(l), P(x), P(x), P(x), P(x), 1, 1, N, d, 0.1, mode,
                                                          P(ws), nb, None)
     assert lib.fa2_backward_fused_workspace_bytes(1, 1, 300, 128) == 0
-    assert lib.fa2_backward_fused_workspace_bytes(1, 1, 256, 64) == 0
+    assert lib.fa2_backward_fused_workspace_bytes(1, 1, 300, 64) == 0
+    assert lib.fa2_backward_fused_workspace_bytes(1, 1, 256, 64) == lib.fa2_backward_fused_workspace_bytes(1, 1, 256, 128)
     assert call(300, 128, 1, ws.numel()) != 0          # not a multiple of 256
-    assert call(256, 64, 1, ws.numel()) != 0           # head_dim 64
+    assert call(300, 64, 1, ws.numel()) != 0           # head_dim 64: aligned lengths only
+    assert call(256, 64, 0, ws.numel()) != 0           # head_dim 64 has no atomics form
     assert call(256, 128, 2, ws.numel()) != 0          # no such mode
     assert call(256, 128, 1, 1024) != 0                # workspace too small
     # bit 3 of fa2_backward_phases on a shape the single kernel does not take
-    x64 = torch.zeros(1, 1, 256, 64, dtype=torch.bfloat16, device="cuda")
-    st = lib.fa2_backward_phases(P(x64), P(x64), P(x64), P(x64), P(l), P(x64), P(x64), P(x64), P(x64), 1, 1, 256, 64, 0.1, 0, 0, P(ws),
+    x64 = torch.zeros(1, 1, 320, 64, dtype=torch.bfloat16, device="cuda")
+    l64 = torch.zeros(1, 1, 320, device="cuda")
+    st = lib.fa2_backward_phases(P(x64), P(x64), P(x64), P(x64), P(l64), P(x64), P(x64), P(x64), P(x64), 1, 1, 320, 64, 0.1, 0, 0, P(ws),
                                  ws.numel(), None, 8)
-    assert st != 0                                     # head_dim 64
+    assert st != 0                                     # head_dim 64, seq_len not a multiple of 256
     for ph in (15, 8 | 2, 8 | 4):                      # bit 3 does not combine with the two-kernel bits
         st = lib.fa2_backward_phases(P(x), P(x), P(x), P(x), P(l), P(x), P(x), P(x), P(x), 1, 1, 256, 128, 0.1, 0, 0, P(ws), ws.numel(), None, ph)
         assert st == -6, (ph, st)

@@ -173,8 +173,8 @@ def test_fused_backward_kernel(asm):
     chained form's bodies carry their four dQ stores in front of the barrier and the four running-sum loads behind it, and
     nothing touches scratch."""
     ks = {n: k for n, k in _kernels(asm["fa2_bwd_fused"]).items() if "fa2_bwd_fused_kernelILb" in n}
-    assert len(ks) == 6          # <atomics>, <chain>, <chain, causal>, the two ragged instantiations of the chained forms, and
-    #                              the rectangular-block one (round 4: the causal ring's unmasked half blocks)
+    assert len(ks) == 8          # <atomics>, <chain>, <chain, causal>, the two ragged instantiations of the chained forms, the
+    #                              rectangular-block one (round 4: the causal ring's unmasked half blocks) and head_dim 64's two
     pat = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
     for name, k in ks.items():
         chain, causal, ragged = "ILb1ELb" in name, "ILb1ELb1ELb" in name, name.split("fa2_bwd_fused_kernelILb")[1][8:9] == "1"
@@ -183,12 +183,14 @@ def test_fused_backward_kernel(asm):
             for m in pat.finditer(s):
                 hi = int(m.group(1)) if m.group(1) else int(m.group(3))
                 assert hi < 39, (name, s)
-        assert k["meta"]["total"] == 512 and k["meta"]["agpr"] == 256, (name, k["meta"])
+        d64 = name.endswith("ELi64EEEvNS_9FusedArgsE")          # the fifth template argument: head_dim
+        per_body, nzero = (40, 8) if d64 else (80, 16)
+        assert k["meta"]["total"] == 512 and k["meta"]["agpr"] == 256, (name, k["meta"])      # (head_dim 64 names a[0:128) and v40..v227 only; the clobber lists are head_dim 128's)
         nb = 24 if (causal or ragged) else 18      # six-body loops inside the unit loop: first, steady state, last, and masked -- the
-        #                                causal diagonal, or the last key block of a ragged sequence; + the 16 accumulator-zeroing MFMAs
-        assert sum("v_mfma_f32_32x32x16_bf16" in l for l in k["body"]) == nb * 80 + 16, name
+        #                                causal diagonal, or the last key block of a ragged sequence; + the accumulator-zeroing MFMAs
+        assert sum("v_mfma_f32_32x32x16_bf16" in l for l in k["body"]) == nb * per_body + nzero, name
         assert not any("scratch_" in l for l in k["body"]), name
-        bodies = [b for b in _split_asm(k["body"])[1] if sum("v_mfma" in s for s in b) == 80]
+        bodies = [b for b in _split_asm(k["body"])[1] if sum("v_mfma" in s for s in b) == per_body]
         assert len(bodies) == nb
         assert sum(any(s.startswith("v_cmp_le_i32 vcc") for s in b) for b in bodies) == (6 if (causal or ragged) else 0)
         for b in bodies:
@@ -202,7 +204,7 @@ def test_fused_backward_kernel(asm):
                 assert all(" sc1" in b[i] for i in ld)
                 # the step's LDS-DMA, progress prefetch and hand-shake are inside the body: 4 + 1 DMA issues in front of the
                 # barrier, the publishing store and the bounded poll loop behind it, in front of the running-sum loads
-                assert len(dma) == 5 and max(dma) < bar[0]
+                assert len(dma) == (3 if d64 else 5) and max(dma) < bar[0]
                 pub = [i for i, s in enumerate(b) if s.startswith("buffer_store_dword v39")]
                 assert len(pub) == 1 and bar[0] < pub[0] < min(ld)
                 assert sum(s.startswith("s_cbranch_scc1 1b") for s in b) == 1
@@ -281,7 +283,7 @@ def test_generated_bodies_pass_the_static_checker(inc):
     spec.loader.exec_module(cb)
     text = open(os.path.join(CSRC, inc)).read()
     names = re.findall(r"#define (FA2_\w+_[CM]?BODY_\w+) ", text)
-    assert len(names) in (12, 16, 18, 24, 120)
+    assert len(names) in (12, 16, 24, 36, 120)
     for n in names:
         assert cb.check(cb.body(text, n), n) == []
 

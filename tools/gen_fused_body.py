@@ -43,30 +43,54 @@ base.GAP_BUDGET = int(os.environ.get("FA2_GEN_BUDGET", str(base.GAP_BUDGET)))
 READ_AHEAD = int(os.environ.get("FA2_GEN_READ_AHEAD", str(base.READ_AHEAD)))
 READ_LATEST = int(os.environ.get("FA2_GEN_READ_LATEST", str(base.READ_LATEST)))
 
-D, KS, DT = 128, 8, 4
-ROWB = 2 * D
-NSLOT = 6
 V0 = 40
-VF, SACC, DPACC, PF, DSF, SLOT = V0, V0 + 64, V0 + 96, V0 + 128, V0 + 144, V0 + 160
-DQT = SLOT + 4 * NSLOT            # 224
-ROFFK = DQT + 16                  # 240
-DSWR = ROFFK + 8                  # 248..251
-DSRD = DSWR + 4                   # 252, 253
-KT = DSRD + 2                     # 254, 255
-assert KT + 2 == 256
-A_DK, A_DV = 0, 128
-# LDS map (bytes)
 KIMG = 0
-QRING = 65536
-BUFB = 2 * 32 * ROWB + 256        # Q tile | dO tile | 32 x (-L/scale), 32 x (-D)
-DSB = QRING + 3 * BUFB            # two dS tiles of 256 keys x 32 q bf16
 DSTILE = 256 * 64
-LDS_BYTES = DSB + 2 * DSTILE
 COST = dict(COST, ldsw=6, vmem=10, cmask=8)
-# The body's one barrier sits right behind MFMA number GBAR: everything that must be out before it (the dS tile's writes, the
-# chained form's dQ stores) has a deadline in front of it, everything that relies on it (reads of the next tile, the loads of
-# the next running sum) is released behind it.
-GBAR = int(os.environ.get("FA2_GEN_GBAR", "72"))
+
+
+def set_dim(d):
+    """Register map, LDS map and stage table for head_dim d (128: the round-2 kernel; 64: round 4).  d = 64: a sub-tile is 40
+    MFMAs -- A 8, B 8, E 8, C 8, D 8 -- and the dQ tile of a sub-tile is 32 x 64: wave w forms columns 32 (w & 1) .. + 31 over
+    the 128 keys of half w >> 1 of the workgroup's 256 (the kernel puts the half into the E address registers), so there are
+    TWO running sums per column block, one per half, each handed from key block to key block like d = 128's one; the
+    output pass adds them."""
+    global D, KS, DT, ROWB, NE, VF, SACC, DPACC, PF, DSF, SLOT, DQT, ROFFK, DSWR, DSRD, KT, VEND, A_DK, A_DV, QRING, BUFB, DSB
+    global LDS_BYTES, GBAR, DQTILE, NS_, PRE, GAP_BUDGET_D, NSLOT
+    D, KS, DT = d, d // 16, d // 32
+    # fragment slots: the rotation must close over a sub-tile AND leave the slots of the next body's first reads free early
+    # (d = 128: 64 takes, six slots; d = 64: 32 takes, eight slots -- with six the last D-stage slot would be the next A's)
+    NSLOT = 6 if D == 128 else 8
+    ROWB = 2 * D
+    NE = 16 if D == 128 else 8            # E's k-steps of 16 keys per wave: all 256 keys (d = 128) or the wave's half (d = 64)
+    VF = V0
+    SACC = VF + 8 * KS
+    DPACC = SACC + 32
+    PF = DPACC + 32
+    DSF = PF + 16
+    SLOT = DSF + 16
+    DQT = SLOT + 4 * NSLOT
+    ROFFK = DQT + 16
+    DSWR = ROFFK + KS
+    DSRD = DSWR + 4
+    KT = DSRD + 2
+    VEND = KT + 2
+    assert VEND <= 256
+    A_DK, A_DV = 0, 32 * DT
+    # LDS map (bytes): K image | ring of three Q / dO tiles | two dS tiles
+    QRING = 256 * ROWB
+    BUFB = 2 * 32 * ROWB + 256        # Q tile | dO tile | 32 x (-L/scale), 32 x (-D)
+    DSB = QRING + 3 * BUFB            # two dS tiles of 256 keys x 32 q bf16
+    LDS_BYTES = DSB + 2 * DSTILE
+    NS_ = 4 * KS + NE + 8 * DT
+    # The body's one barrier sits right behind MFMA number GBAR: everything that must be out before it (the dS tile's writes,
+    # the chained form's dQ stores) has a deadline in front of it, everything that relies on it (reads of the next tile, the
+    # loads of the next running sum) is released behind it.
+    GBAR = int(os.environ.get("FA2_GEN_GBAR" if D == 128 else "FA2_GEN_GBAR64", str(NS_ - 8 if D == 128 else NS_ - 5)))
+    DQTILE = f"v[{DQT}:{DQT + 15}]"
+    PRE = "FA2_FUSED" if D == 128 else "FA2_FUSED64"
+    # d = 64: the same VALU work per sub-tile beside half the MFMAs -- the gaps carry more than a 32-clock MFMA hides
+    GAP_BUDGET_D = base.GAP_BUDGET if D == 128 else int(os.environ.get("FA2_GEN_BUDGET64", "44"))
 # where the next tile's LDS-DMA pieces may be issued (gaps): the guide prices a piece at ~60 clocks among bare MFMAs, 100 - 185
 # in a phase full of ds_read_b128, 25 - 60 in VALU-only gaps
 DMA_REL = int(os.environ.get("FA2_GEN_DMA_REL", "1"))
@@ -88,7 +112,9 @@ def slot_lo(i): b = SLOT + 4 * i; return f"v[{b}:{b + 1}]"
 def slot_hi(i): b = SLOT + 4 * i + 2; return f"v[{b}:{b + 1}]"
 def dk(kb, dt): b = A_DK + 16 * (kb * DT + dt); return f"a[{b}:{b + 15}]"
 def dv(kb, dt): b = A_DV + 16 * (kb * DT + dt); return f"a[{b}:{b + 15}]"
-DQTILE = f"v[{DQT}:{DQT + 15}]"
+
+
+set_dim(128)
 
 
 # packed multiplies (v_pk_mul_f32 for the two scalings of a register pair): MEASURED SLOWER -- 971K instead of 882K cycles per
@@ -108,15 +134,17 @@ ABL = set(x for x in os.environ.get("FA2_GEN_ABL", "").split(",") if x)
 
 
 def build(chain=False, masked=False):
-    NS = 80
-    gA1, gB, gC, gD = KS + 1, 16, 48, 64
+    NS = NS_
+    gA1, gB = KS + 1, 2 * KS
+    gC = gB + 2 * KS + NE
+    gD = gC + 4 * DT
     # B (dP', one dO fragment per pair of MFMAs: light on the LDS) and E (four transposed reads per MFMA: with all four
-    # waves in it at once, exactly what the LDS array can deliver) share gaps 16..47: the first four B pairs, then four
-    # groups of [B pair, four E steps] -- 75 % of the array instead of 25 % followed by 100 %.
+    # waves in it at once, exactly what the LDS array can deliver) share the gaps between A and C: the first half of the B
+    # pairs, then groups of [B pair, four E steps] -- 75 % of the array instead of 25 % followed by 100 %.
     ILV = os.environ.get("FA2_GEN_ILV", "1") == "1"
-    def gBp(sidx): return (gB + 2 * sidx) if (not ILV or sidx < 4) else (24 + 6 * (sidx - 4))
-    def gEs(sidx): return (32 + sidx) if not ILV else (24 + 6 * (sidx // 4) + 2 + sidx % 4)
-    gEend = gEs(15) + 1
+    def gBp(sidx): return (gB + 2 * sidx) if (not ILV or sidx < KS // 2) else (gB + KS + 6 * (sidx - KS // 2))
+    def gEs(sidx): return (gB + 2 * KS + sidx) if not ILV else (gB + KS + 6 * (sidx // 4) + 2 + sidx % 4)
+    gEend = gEs(NE - 1) + 1
     mfma = [None] * NS
     tasks = []
     ctr = [0]
@@ -171,8 +199,8 @@ def build(chain=False, masked=False):
         # through the regular slots; the dS fragments land in the four DSF tuples, which are idle from the previous body's D
         # stage to this body's dS packs (so E reads five MFMAs ahead instead of three).
         # (fragment slots are handed out in the order of use: the two stages interleave)
-        xbusy = [gD - NS + 6, gD - NS + 7, gD - NS + 14, gD - NS + 15]      # last D-stage readers of dsf(0,0), (1,0), (0,1), (1,1)
-        for g, kind, s in sorted([(gBp(i), "B", i) for i in range(KS)] + [(gEs(i), "E", i) for i in range(16)]):
+        xbusy = [gD - NS + 2 * DT - 2, gD - NS + 2 * DT - 1, gD - NS + 4 * DT - 2, gD - NS + 4 * DT - 1]      # last D-stage readers of dsf(0,0), (1,0), (0,1), (1,1)
+        for g, kind, s in sorted([(gBp(i), "B", i) for i in range(KS)] + [(gEs(i), "E", i) for i in range(NE)]):
             if kind == "B":
                 sg, fg = take(g + 1)
                 if rec:
@@ -299,10 +327,10 @@ def build(chain=False, masked=False):
         # LDS-DMA of the next Q / dO tile (two 1-KiB pieces of each per wave; waves 0 and 1 also fetch the 32 + 32 row
         # constants) and the prefetch of the previous key block's progress word into v39.
         for which in (0, 1):
-            for i in (0, 1):
+            for i in range(ROWB // 128):           # 1-KiB pieces of a 32-row tile per wave: two at d = 128, one at d = 64
                 rs = "%[grs]" if which else "%[qrs]"
                 mid = f"s_add_u32 s12, %[qso], {4096 * i}" if i else "s_nop 0"
-                tasks.append(Task(f"s_add_u32 m0, %[mw], @NB+{8192 * which + 4096 * i}\n\t{mid}\n\t"
+                tasks.append(Task(f"s_add_u32 m0, %[mw], @NB+{32 * ROWB * which + 4096 * i}\n\t{mid}\n\t"
                                   f"buffer_load_dwordx4 %[dvo], {rs}, {'s12' if i else '%[qso]'} offen{DMA_POLICY} lds", COST["vmem"] + 2, DMA_REL, DMA_DL, "vmem",
                                   ("dma", which, i)))
         tasks.append(Task(f"s_cmp_lt_u32 %[wv], 2\n\ts_cbranch_scc0 4f\n\ts_mov_b64 exec, 0xffffffff\n\ts_add_u32 m0, %[mw2], @NB+{2 * 32 * ROWB}\n\t"
@@ -310,7 +338,7 @@ def build(chain=False, masked=False):
                           "vmem", ("dma", "rc")))
         # the progress prefetch is issued late (its round trip is ~900 clocks, the barrier behind which it is read sits at
         # gap 72): the staler the prefetched word, the further behind its predecessor a key block has to run
-        pg = int(os.environ.get("FA2_GEN_SEEN_GAP", "42"))
+        pg = int(os.environ.get("FA2_GEN_SEEN_GAP", str(GBAR - 30))) if D == 128 else int(os.environ.get("FA2_GEN_SEEN_GAP64", str(GBAR - 20)))
         tasks.append(Task("buffer_load_dword v39, off, %[ctl], %[pvo] sc1", COST["vmem"], pg, pg + 4, "vmem", ("seen",)))
         st = [Task(f"buffer_store_dwordx4 v[{DQT + 4 * g}:{DQT + 4 * g + 3}], %[dqv], %[drs], %[dso] offen offset:{1024 * g}", COST["vmem"],
                    gEend + 3, min(gEend + 8, GBAR - 1), "vmem", ("dqst", g)) for g in range(4)]
@@ -423,47 +451,57 @@ def resolve(lines, buf, par, chain=False, prologue=False):
     return out
 
 
+def emit(check):
+    """The chunks of the .inc for the head_dim set_dim() selected (or, with check, the schedule's per-gap load)."""
+    mfma, tasks, NS = build()
+    per_gap, load = base.place(tasks, NS, budget=GAP_BUDGET_D)
+    lines, pro = render_lines(mfma, per_gap, NS)
+    cm, ct, _ = build(chain=True)
+    cper_gap, cload = base.place(ct, NS, budget=GAP_BUDGET_D)
+    clines, cpro = render_lines(cm, cper_gap, NS)
+    assert cpro == pro
+    # the causal kernel's bodies for the tiles around the diagonal: rare (at most 18 per unit), so they may run over the
+    # issue budget of a gap; what they leave in flight for the next body is the same as the plain ones' (they alternate)
+    mm, mt, _ = build(chain=True, masked=True)
+    mper_gap, mload = base.place(mt, NS, budget=GAP_BUDGET_D + 8)
+    mlines, mpro = render_lines(mm, mper_gap, NS)
+    assert mpro == pro
+    if check:
+        print("   chained load:", " ".join(str(l) for l in cload))
+        print("   masked  load:", " ".join(str(l) for l in mload))
+        print(f"fused D={D}: {len(lines)} lines, {sum('v_mfma' in l for l in lines)} MFMAs, {len(pro)} early, max gap load {max(load)}, "
+              f"{sum(l > GAP_BUDGET_D for l in load)} of {NS} gaps over {GAP_BUDGET_D}")
+        print("   load:", " ".join(str(l) for l in load))
+        return []
+    chunks = [f"#define {PRE}_VF {VF}\n#define {PRE}_DQT {DQT}\n#define {PRE}_ROFFK {ROFFK}\n#define {PRE}_DSWR {DSWR}\n"
+              f"#define {PRE}_DSRD {DSRD}\n#define {PRE}_KT {KT}\n#define {PRE}_QRING {QRING}\n#define {PRE}_BUFB {BUFB}\n"
+              f"#define {PRE}_DSB {DSB}\n#define {PRE}_DSTILE {DSTILE}\n#define {PRE}_LDS {LDS_BYTES}\n"
+              + (f"#define FA2_FUSED_SPIN_LIMIT {SPIN_LIMIT}\n" if D == 128 else "")]
+    p = resolve(pro, 2, 1, prologue=True)      # 'next' of (buffer 2, parity 1) = (0, 0)
+    p.append("s_waitcnt lgkmcnt(0)")
+    chunks.append(f"#define {PRE}_PRO \\\n" + base.c_string(p) + "\n")
+    for buf in range(3):
+        for par in range(2):
+            chunks.append(f"#define {PRE}_BODY_B{buf}_P{par} \\\n" + base.c_string(resolve(lines, buf, par)) + "\n")
+            chunks.append(f"#define {PRE}_CBODY_B{buf}_P{par} \\\n" + base.c_string(resolve(clines, buf, par, chain=True)) + "\n")
+            chunks.append(f"#define {PRE}_MBODY_B{buf}_P{par} \\\n" + base.c_string(resolve(mlines, buf, par, chain=True)) + "\n")
+    return chunks
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "cuda_flashattention_amd", "csrc",
                                                   "fa2_bwd_fused_body.inc"))
     args = ap.parse_args()
-    mfma, tasks, NS = build()
-    per_gap, load = base.place(tasks, NS)
-    lines, pro = render_lines(mfma, per_gap, NS)
-    cm, ct, _ = build(chain=True)
-    cper_gap, cload = base.place(ct, NS)
-    clines, cpro = render_lines(cm, cper_gap, NS)
-    assert cpro == pro
-    # the causal kernel's bodies for the tiles around the diagonal: rare (at most 18 per unit), so they may run over the
-    # issue budget of a gap; what they leave in flight for the next body is the same as the plain ones' (they alternate)
-    mm, mt, _ = build(chain=True, masked=True)
-    mper_gap, mload = base.place(mt, NS, budget=base.GAP_BUDGET + 8)
-    mlines, mpro = render_lines(mm, mper_gap, NS)
-    assert mpro == pro
-    if args.check:
-        print("   chained load:", " ".join(str(l) for l in cload))
-        print("   masked  load:", " ".join(str(l) for l in mload))
-        print(f"fused D=128: {len(lines)} lines, {sum('v_mfma' in l for l in lines)} MFMAs, {len(pro)} early, max gap load {max(load)}, "
-              f"{sum(l > base.GAP_BUDGET for l in load)} of {NS} gaps over {base.GAP_BUDGET}")
-        print("   load:", " ".join(str(l) for l in load))
-        return
     chunks = ["// GENERATED by tools/gen_fused_body.py -- do not edit.  Main-loop bodies of the single-kernel five-product backward:\n"
               "// FA2_FUSED_{BODY,CBODY,MBODY}_B<ring buffer>_P<dS tile parity> (atomics form / chained / chained + causal mask), prologue\n"
-              "// FA2_FUSED_PRO.  Register and LDS maps: the generator.\n",
-              f"#define FA2_FUSED_VF {VF}\n#define FA2_FUSED_DQT {DQT}\n#define FA2_FUSED_ROFFK {ROFFK}\n#define FA2_FUSED_DSWR {DSWR}\n"
-              f"#define FA2_FUSED_DSRD {DSRD}\n#define FA2_FUSED_KT {KT}\n#define FA2_FUSED_QRING {QRING}\n#define FA2_FUSED_BUFB {BUFB}\n"
-              f"#define FA2_FUSED_DSB {DSB}\n#define FA2_FUSED_DSTILE {DSTILE}\n#define FA2_FUSED_LDS {LDS_BYTES}\n"
-              f"#define FA2_FUSED_SPIN_LIMIT {SPIN_LIMIT}\n"]
-    p = resolve(pro, 2, 1, prologue=True)      # 'next' of (buffer 2, parity 1) = (0, 0)
-    p.append("s_waitcnt lgkmcnt(0)")
-    chunks.append("#define FA2_FUSED_PRO \\\n" + base.c_string(p) + "\n")
-    for buf in range(3):
-        for par in range(2):
-            chunks.append(f"#define FA2_FUSED_BODY_B{buf}_P{par} \\\n" + base.c_string(resolve(lines, buf, par)) + "\n")
-            chunks.append(f"#define FA2_FUSED_CBODY_B{buf}_P{par} \\\n" + base.c_string(resolve(clines, buf, par, chain=True)) + "\n")
-            chunks.append(f"#define FA2_FUSED_MBODY_B{buf}_P{par} \\\n" + base.c_string(resolve(mlines, buf, par, chain=True)) + "\n")
+              "// FA2_FUSED_PRO; the same with the prefix FA2_FUSED64_ for head_dim 64.  Register and LDS maps: the generator.\n"]
+    for d in (128, 64):
+        set_dim(d)
+        chunks += emit(args.check)
+    if args.check:
+        return
     with open(args.out, "w") as f:
         f.write("\n".join(chunks))
     print("wrote", args.out)
