@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(39))) f
 {
     static_assert(CHAIN || !RAGGED, "the atomics form has no ragged variant");
     static_assert(!RECT || (CHAIN && !CAUSAL && !RAGGED), "rectangular blocks: chained, unmasked, aligned");
-    static_assert(HD == 128 || (HD == 64 && CHAIN && !RAGGED && !RECT), "head_dim 64: chained, aligned, square");
+    static_assert(HD == 128 || (HD == 64 && CHAIN && !RECT), "head_dim 64: chained, square");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const BwdArgs& p = fp.b;
     constexpr int D = HD, ROWB = 2 * D, KS = D / 16, DT = D / 32;
@@ -727,11 +727,11 @@ __global__ void __launch_bounds__(256) fa2_bwd_fused_dq_out_chain_kernel(const f
 // summed over the keys of half wave >> 1 of every key block: dQ = scale x (the sum of half 0 + the sum of half 1).  n4h = BH x
 // (N / 32) x 2 column blocks x 4 x 64 threads' worth.
 __global__ void __launch_bounds__(256) fa2_bwd_fused_dq_out_chain64_kernel(const float* __restrict__ acc, __bf16* __restrict__ dQ, size_t n4h, float scale,
-                                                                            const int* __restrict__ err, int N)
+                                                                            const int* __restrict__ err, int N, int NP)
 {
     const float poison = *err ? __builtin_nanf("") : 0.0f;
     const size_t stride = (size_t)gridDim.x * 256;
-    const size_t tiles = (size_t)(N / 32);
+    const size_t tiles = (size_t)(NP / 32);      // NP = N rounded up to 256: rows >= N are not stored
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4h; i += stride) {
         const int lane = (int)(i & 63), g = (int)((i >> 6) & 3), cbk = (int)((i >> 8) & 1);
         const size_t tg = i >> 9, head = tg / tiles;
@@ -740,7 +740,8 @@ __global__ void __launch_bounds__(256) fa2_bwd_fused_dq_out_chain64_kernel(const
         const int row = (int)(tg % tiles) * 32 + 8 * g + 4 * (lane >> 5);
         __bf16* o = dQ + (head * (size_t)N + row) * 64 + 32 * cbk + (lane & 31);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[(size_t)e * 64] = (__bf16)((a[e] + b[e]) * scale + poison);
+        for (int e = 0; e < 4; ++e)
+            if (row + e < N) o[(size_t)e * 64] = (__bf16)((a[e] + b[e]) * scale + poison);
     }
 }
 
@@ -801,7 +802,7 @@ hipError_t launch_bwd_fused_bf16(const BwdArgs& a, float* dQacc, int* ctl, int m
     // no mask, both lengths aligned; everything else is the dense square problem
     const bool rect = a.Nq != a.Nk || a.q_hs != a.Nq || a.k_hs != a.Nk || a.q_row0 != 0;
     if ((a.d != 128 && a.d != 64) || a.Nk < 1 || a.Nq < 1) return hipErrorInvalidValue;
-    if (a.d == 64 && (mode != 1 || ragged || rect)) return hipErrorInvalidValue;          // head_dim 64: chained, aligned, square
+    if (a.d == 64 && (mode != 1 || rect)) return hipErrorInvalidValue;          // head_dim 64: chained, square
     if (rect && (mode != 1 || a.causal || ragged || a.Nq % 32 != 0 || a.q_row0 < 0 || a.q_hs < a.q_row0 + a.Nq || a.k_hs < a.Nk))
         return hipErrorInvalidValue;
     if (ragged && (mode != 1 || !rcpad)) return hipErrorInvalidValue;
@@ -858,8 +859,16 @@ hipError_t launch_bwd_fused_bf16(const BwdArgs& a, float* dQacc, int* ctl, int m
         if (g_hook_grid >= 1 && g_hook_grid < wgs) wgs = g_hook_grid;
         FA2_HOOK_NOTE_GRID(wgs);
         const dim3 grid((unsigned)wgs);
-        static bool set_cr[64] = {}, set_tr[64] = {}, set_re[64] = {}, set_64[64] = {}, set_64c[64] = {};
-        if (a.d == 64 && a.causal) {
+        static bool set_cr[64] = {}, set_tr[64] = {}, set_re[64] = {}, set_64[64] = {}, set_64c[64] = {}, set_64r[64] = {}, set_64cr[64] = {};
+        if (a.d == 64 && a.causal && ragged) {
+            e = ensure_dynamic_lds(fa2_bwd_fused_kernel<true, true, true, false, 64>, lds, set_64cr);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((fa2_bwd_fused_kernel<true, true, true, false, 64>), grid, dim3(256), lds, stream, fa);
+        } else if (a.d == 64 && ragged) {
+            e = ensure_dynamic_lds(fa2_bwd_fused_kernel<true, false, true, false, 64>, lds, set_64r);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((fa2_bwd_fused_kernel<true, false, true, false, 64>), grid, dim3(256), lds, stream, fa);
+        } else if (a.d == 64 && a.causal) {
             e = ensure_dynamic_lds(fa2_bwd_fused_kernel<true, true, false, false, 64>, lds, set_64c);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL((fa2_bwd_fused_kernel<true, true, false, false, 64>), grid, dim3(256), lds, stream, fa);
@@ -896,7 +905,7 @@ hipError_t launch_bwd_fused_bf16(const BwdArgs& a, float* dQacc, int* ctl, int m
                            (const int*)nullptr);
     else if (a.d == 64)
         hipLaunchKernelGGL(fa2_bwd_fused_dq_out_chain64_kernel, dim3(4096), dim3(256), 0, stream, dQacc, (__bf16*)a.dQ, elems / 8, a.scale,
-                           ctl + kCtlError, a.Nk);
+                           ctl + kCtlError, a.Nk, npad);
     else
         hipLaunchKernelGGL(fa2_bwd_fused_dq_out_chain_kernel, dim3(4096), dim3(256), 0, stream, dQacc, (__bf16*)a.dQ, elems / 4, a.scale,
                            ctl + kCtlError, rect ? a.Nq : a.Nk, rect ? a.Nq : npad, rect ? a.q_hs : a.Nk);

@@ -132,8 +132,9 @@ size_t fa2_backward_workspace_bytes(int B, int H, int seq_len, int head_dim, int
  *     the end masked, rows past the end given row constants that make P vanish, nothing past the end stored); it is taken
  *     whenever that padding costs less than the two extra products of the other form: 5 roundup(N, 256) <= 7 roundup(N, 64),
  *     i.e. every multiple of 256, every N >= 897 and the lengths just below a multiple of 256 under that;
- *   - bf16, head_dim 64, seq_len a multiple of 256 (causal or not; round 4): the same kernel built for head_dim 64 (a sub-tile's
- *     dQ tile is summed in two key halves, i.e. two running sums per column block);
+ *   - bf16, head_dim 64 (causal or not; round 4): the same kernel built for head_dim 64 (a sub-tile's dQ tile is summed in two
+ *     key halves, i.e. two running sums per column block), taken when 13 roundup(N, 256) <= 14 roundup(N, 64) -- it is ~10 %
+ *     ahead of the other form there, so the padding may cost 7 %: every multiple of 256, the lengths just below, every N >= 3329;
  *   - everything else: a dQ kernel and a dK/dV kernel (seven products, csrc/fa2_bwd_bf16.hip).
  * The environment variable FA2_BACKWARD_PATH=two_kernel keeps every shape on the second form.
  * PLACEMENT ASSUMPTION of the first form: its workgroups read HW_REG_XCC_ID and hand running sums to each other through the

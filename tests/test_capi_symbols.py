@@ -64,7 +64,7 @@ def test_argument_checking_status_codes():
     # d = 64 (round 4): aligned lengths run the single kernel too -- the same running-sum layout (128 floats per row: four waves x
     # 32 columns, two key halves per column block) and control block as d = 128; other lengths the two kernels
     assert lib.fa2_backward_workspace_bytes(4, 16, 8192, 64, 0) == lib.fa2_backward_workspace_bytes(4, 16, 8192, 128, 0)
-    assert lib.fa2_backward_workspace_bytes(4, 16, 8200, 64, 0) == 3 * ((4 * 16 * 8200 * 4 + 255) // 256 * 256)
+    assert lib.fa2_backward_workspace_bytes(4, 16, 800, 64, 0) == 3 * ((4 * 16 * 800 * 4 + 255) // 256 * 256)      # 1024 against 832: two kernels
     assert lib.fa2_backward_workspace_bytes(4, 16, 8192, 128, 1) == base         # fp32
     fused = lib.fa2_backward_workspace_bytes(4, 16, 8192, 128, 0)                # + fp32 dQ sums + a control block
     assert base + 4 * 16 * 8192 * 128 * 4 < fused < base + 4 * 16 * 8192 * 128 * 4 + (1 << 20)

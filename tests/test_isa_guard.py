@@ -173,8 +173,8 @@ def test_fused_backward_kernel(asm):
     chained form's bodies carry their four dQ stores in front of the barrier and the four running-sum loads behind it, and
     nothing touches scratch."""
     ks = {n: k for n, k in _kernels(asm["fa2_bwd_fused"]).items() if "fa2_bwd_fused_kernelILb" in n}
-    assert len(ks) == 8          # <atomics>, <chain>, <chain, causal>, the two ragged instantiations of the chained forms, the
-    #                              rectangular-block one (round 4: the causal ring's unmasked half blocks) and head_dim 64's two
+    assert len(ks) == 10         # <atomics>, <chain>, <chain, causal>, the two ragged instantiations of the chained forms, the
+    #                              rectangular-block one (round 4: the causal ring's unmasked half blocks) and head_dim 64's four
     pat = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
     for name, k in ks.items():
         chain, causal, ragged = "ILb1ELb" in name, "ILb1ELb1ELb" in name, name.split("fa2_bwd_fused_kernelILb")[1][8:9] == "1"
