@@ -281,6 +281,23 @@ def main():
             msc = median_ms(causal_step, torch, 3, 10)
             extra["fwd_bwd_bf16_causal_(4,16,8192,128)"] = {"ms": round(msc, 4), "tflops": round(7.0 * B * H * N * N * D / msc / 1e9, 1),
                                                             "timing": "median of 3 x 10 steps after 10 warm-up steps"}
+            # the backward at head_dim 64 (round 4: the single kernel built for d = 64) beside the two-kernel form it replaced
+            def bwd64():
+                Bx, Hx, Nx, dx = 4, 16, 8192, 64
+                mkx = lambda s: ((torch.rand(Bx, Hx, Nx, dx, device=dev) - 0.5) * s).to(torch.bfloat16)
+                q, k, v, g_ = mkx(1.0), mkx(1.0), mkx(1.0), mkx(0.4)
+                o, l = fa.flash_attention_2_forward(q, k, v)
+                w = torch.empty(fa._capi.lib().fa2_backward_workspace_bytes(Bx, Hx, Nx, dx, 0), dtype=torch.uint8, device=dev)
+                gq, gk, gv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+                run = lambda ph: fa.flash_attention_2_backward(q, k, v, o, l, g_, dQ=gq, dK=gk, dV=gv, workspace=w, phases=ph)
+                for _ in range(5):
+                    run(7)
+                one = median_ms(lambda: run(7), torch, 3, 10)
+                two = median_ms(lambda: run(1), torch, 3, 10) + median_ms(lambda: run(2), torch, 3, 10) + median_ms(lambda: run(4), torch, 3, 10)
+                fl = 10.0 * Bx * Hx * Nx * Nx * dx
+                return {"ms": round(one, 4), "tflops": round(fl / one / 1e9, 1), "two_kernel_form_ms": round(two, 4),
+                        "timing": "fa2_backward (delta + single kernel + output pass), median of 3 x 10 launches; flops = 10 B H N^2 d"}
+            extra["bwd_bf16_d64_(4,16,8192,64)"] = bwd64()
             fwd()                                                    # leave O, L as the non-causal forward's
             # the reference's FlashAttention-1 step restated (scalar fp32, one head, no MFMA): a DIDACTIC row, not a target
             Nf, df = 4096, 64

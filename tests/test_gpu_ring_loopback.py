@@ -273,6 +273,16 @@ def test_ring_backward_real_local_lengths_single_kernel_chains(P, n, H, causal):
         assert st == 0, st
 
 
+@pytest.mark.parametrize("causal", [False, True], ids=["plain", "causal"])
+def test_ring_backward_d64_aligned_local_length(causal):
+    """d = 64 at a local length of 512: the dense square blocks run the single kernel built for head_dim 64 (round 4), under
+    FA2_PHASE_LEAVE_CUS, the causal ring's half blocks the two kernels (the rectangular instantiation is head_dim 128's)."""
+    got, ref = _backward(2, 1, 3, 1024, 64, causal, seed=43)
+    for a, b, name in zip(got, ref, ("dQ", "dK", "dV")):
+        assert np.isfinite(a).all(), name
+        assert np.linalg.norm(a - b) / np.linalg.norm(b) < 5e-3, name
+
+
 def test_ring_backward_d64_ragged_local_length():
     """d = 64 and a local length that is not a multiple of any tile (n = 200): tail masking inside the block kernels."""
     got, ref = _backward(4, 1, 2, 800, 64, False, seed=41)
