@@ -788,7 +788,7 @@ hipError_t bwd_fused_read_error(const int* ctl, int* err, hipStream_t stream)
 // a backward on this workspace that runs no hand-off (the two kernels, the atomics form): the error word then says so
 hipError_t bwd_fused_clear_error(int* ctl, hipStream_t stream)
 {
-    return hipMemsetAsync(ctl + kCtlError, 0, sizeof(int), stream);
+    return launch_fill_f32(reinterpret_cast<float*>(ctl + kCtlError), 1, 0.0f, stream);      // (a kernel, not hipMemsetAsync: see the launcher)
 }
 
 // (the last 8 ints per unit are only written by -DFA2_FUSED_STATS builds: tools/gpu_stats_fused.py)
@@ -828,7 +828,7 @@ hipError_t launch_bwd_fused_bf16(const BwdArgs& a, float* dQacc, int* ctl, int m
     FusedArgs fa{a, dQacc, ctl, npad, ragged ? (const float*)rcpad : (const float*)a.RC, g_hook_fault};
     const int lds = (a.d == 64 ? FA2_FUSED64_LDS : FA2_FUSED_LDS) + 16;
     if (mode == 0) {
-        e = hipMemsetAsync(dQacc, 0, elems * 4, stream);
+        e = launch_fill_f32(dQacc, elems, 0.0f, stream);
         if (e != hipSuccess) return e;
         e = bwd_fused_clear_error(ctl, stream);
         if (e != hipSuccess) return e;
@@ -846,7 +846,11 @@ hipError_t launch_bwd_fused_bf16(const BwdArgs& a, float* dQacc, int* ctl, int m
             e = hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev);
             if (e != hipSuccess) return e;
         }
-        e = hipMemsetAsync(ctl, 0, bwd_fused_ctl_bytes(a.BH, a.Nk), stream);
+        // The control block is zeroed by a KERNEL (0.0f is the all-zero word), not by hipMemsetAsync: captured into a HIP graph the
+        // memset node of the 81 KB block of the bench shape did not take effect on replay (round 4: the replayed step ran in
+        // 1.8 ms -- the stale unit queues read "exhausted" and the grid left at once, dQ / dK / dV untouched -- while the 4 KB block of
+        // the (1,4,1024,128) test replayed fine).  A kernel node replays like any other launch.
+        e = launch_fill_f32(reinterpret_cast<float*>(ctl), bwd_fused_ctl_bytes(a.BH, a.Nk) / sizeof(float), 0.0f, stream);
         if (e != hipSuccess) return e;
         static bool set_t[64] = {}, set_c[64] = {};
         // a.reserve_cus: the ring backward's exchanges (RCCL kernels on the communication stream) must find a CU while this

@@ -610,6 +610,50 @@ def test_forward_backward_capture_into_hip_graph():
         assert torch.equal(a, b)
 
 
+def test_graph_replay_at_the_bench_shape():
+    """The same at (4,16,8192,128), where the single-kernel backward's control block is 81 KB: round 4 found that a captured
+    hipMemsetAsync of that block did not take effect on replay (the grid saw stale, exhausted unit queues and left at once:
+    a "step" of 1.8 ms with dQ / dK / dV untouched); the block is now zeroed by a kernel.  Replay must reproduce the eager
+    results bit for bit -- with the outputs cleared in between -- and take about as long as the eager step."""
+    import time
+    fa = _fa()
+    B, H, N, d = 4, 16, 8192, 128
+    g = torch.Generator(device="cuda").manual_seed(5)
+    mk = lambda sc: ((torch.rand(B, H, N, d, device="cuda", generator=g) - 0.5) * sc).bfloat16()
+    Q, K, V, dO = mk(1.0), mk(1.0), mk(1.0), mk(0.4)
+    O = torch.empty_like(Q)
+    L = torch.empty(B, H, N, device="cuda")
+    outs = [torch.empty_like(Q) for _ in range(3)]
+    ws = torch.empty(fa._capi.lib().fa2_backward_workspace_bytes(B, H, N, d, 0), dtype=torch.uint8, device="cuda")
+
+    def step():
+        fa.flash_attention_2_forward(Q, K, V, O=O, L=L)
+        fa.flash_attention_2_backward(Q, K, V, O, L, dO, dQ=outs[0], dK=outs[1], dV=outs[2], workspace=ws)
+    step()
+    torch.cuda.synchronize()
+    ref = [t.clone() for t in [O, L] + outs]
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    for _ in range(2):
+        for t in [O, L] + outs:
+            t.zero_()
+        graph.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(ref, [O, L] + outs):
+        assert torch.equal(a, b)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        graph.replay()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 10 * 1e3
+    assert 5.0 < ms < 8.0, ms          # the whole step ran (the bug's replay took 1.8 ms)
+
+
 @pytest.mark.parametrize("dtype,N,causal,gate", [
     ("bf16", 65536, False, BF16_REL),      # the ring config's whole sequence on one GPU (BASELINE configs[3] at P = 1)
     ("bf16", 65536, True, BF16_REL),
