@@ -104,6 +104,7 @@ def case(B, H, N, seed=0):
     (1, 3, 768),       # 3 heads: not a multiple of the XCD count
     (1, 9, 2048),
     (1, 70, 256),      # more heads than one round of the per-XCD queues
+    (3, 100, 512),     # 300 heads: ~37 chains per queue, a head count that is no multiple of anything
 ])
 def test_fused_backward_vs_oracle(B, H, N, mode):
     import oracle
@@ -246,6 +247,7 @@ def test_bench_shape_matches_the_two_kernel_form():
     (1, 9, 2048),
     (1, 17, 1024),     # 17 heads: the queues take their units in groups of two heads (round 4), and one group has a single head
     (2, 16, 768),      # 32 heads: two full groups per queue
+    (3, 100, 512),     # 300 heads: ~19 groups per queue, the last one of some queue partial
     (1, 2, 16384),     # 64 key blocks per head
 ])
 def test_causal_fused_backward(B, H, N):

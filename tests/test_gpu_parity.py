@@ -11,6 +11,8 @@ Tolerances (stated here, DESIGN.md "Tolerances"):
       1e-4 on the 4x4 forward (main.cu:247), 1e-3 on the 4x4 backward (main.cu:172-178),
       5e-3 on the random cases -- and in fact <= 2e-5 everywhere.
 """
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -608,6 +610,58 @@ def test_forward_backward_capture_into_hip_graph():
     torch.cuda.synchronize()
     for a, b in zip(ref, (O2, L2, dQ2, dK2, dV2)):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_backward_at_the_longest_sequence_sampled(causal):
+    """The backward at the longest sequence BASELINE names (N = 65536, d = 128: 256 key blocks per head, 2048 sub-tiles per unit, a
+    hand-off chain eight times the bench shape's): 48 sampled query rows (dQ) and 48 sampled keys (dK, dV) of one head against the
+    fp64 formulas -- each sample costs O(N d) -- fed the forward's O and L (themselves checked against the oracle on sampled rows
+    by test_long_sequences_sampled_rows); every output finite; fa2_backward_status OK."""
+    fa = _fa()
+    B, H, N, d = 1, 2, 65536, 128
+    g = torch.Generator(device="cuda").manual_seed(655)
+    mk = lambda sc: ((torch.rand(B, H, N, d, device="cuda", generator=g) - 0.5) * sc).bfloat16()
+    Q, K, V, dO = mk(1.0), mk(1.0), mk(1.0), mk(0.4)
+    s = 1.0 / d ** 0.5
+    O, L = fa.flash_attention_2_forward(Q, K, V, s, causal=causal)
+    lib = fa._capi.lib()
+    ws = torch.empty(lib.fa2_backward_workspace_bytes(B, H, N, d, 0), dtype=torch.uint8, device="cuda")
+    dQ, dK, dV = fa.flash_attention_2_backward(Q, K, V, O, L, dO, s, causal=causal, workspace=ws)
+    assert lib.fa2_backward_status(ctypes.c_void_p(ws.data_ptr()), ws.numel(), B, H, N, d, 0,
+                                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    for t in (dQ, dK, dV):
+        assert bool(torch.isfinite(t.float()).all())
+    h = 1
+    q, k, v, go, o = (t[0, h].double().cpu().numpy() for t in (Q, K, V, dO, O))
+    lse = L[0, h].double().cpu().numpy()
+    Dv = (go * o).sum(1)
+    rng = np.random.default_rng(3)
+    rows = np.sort(rng.choice(N, 48, replace=False))
+    keys = np.sort(rng.choice(N, 48, replace=False))
+    idx = np.arange(N)
+    num = {"dQ": 0.0, "dK": 0.0, "dV": 0.0}
+    den = dict(num)
+    gq, gk, gv = (t[0, h].double().cpu().numpy() for t in (dQ, dK, dV))
+    for i in rows:
+        p = np.exp(s * (k @ q[i]) - lse[i])
+        if causal:
+            p[idx > i] = 0.0
+        ds = p * (v @ go[i] - Dv[i])
+        want = s * (ds @ k)
+        num["dQ"] += ((gq[i] - want) ** 2).sum(); den["dQ"] += (want ** 2).sum()
+    for j in keys:
+        p = np.exp(s * (q @ k[j]) - lse)
+        if causal:
+            p[idx < j] = 0.0
+        wv = p @ go
+        ds = p * (go @ v[j] - Dv)
+        wk = s * (ds @ q)
+        num["dV"] += ((gv[j] - wv) ** 2).sum(); den["dV"] += (wv ** 2).sum()
+        num["dK"] += ((gk[j] - wk) ** 2).sum(); den["dK"] += (wk ** 2).sum()
+    errs = {n: float(np.sqrt(num[n] / den[n])) for n in num}
+    print(f"backward at N = 65536 causal={causal}: sampled rel-L2 {errs}")
+    assert all(e <= BF16_REL for e in errs.values()), errs
 
 
 def test_graph_replay_at_the_bench_shape():
