@@ -1,7 +1,11 @@
 // fa2_bwd_fused.hip -- the single-kernel, five-product FlashAttention-2 backward for gfx950: what fa2_backward runs for
-// bf16, d = 128, seq_len a multiple of 256, causal or not (everything else: the dQ and dK/dV kernels of fa2_bwd_bf16.hip).
+// bf16, causal or not, at d = 128 (every seq_len from 897 up and every multiple of 256; padded to the key block inside: RAGGED)
+// and, since round 4, at d = 64 (HD = 64: every seq_len whose padding costs under 7 %), and what fa2_backward_block runs for the
+// ring backward's dense square and unmasked rectangular blocks (RECT).  Everything else -- short ragged lengths, masked
+// rectangular blocks -- runs the dQ and dK/dV kernels of fa2_bwd_bf16.hip.
 // Replaces the reference's flash_attention_2_backward_kernel (02_flash_attention_v2_backward/
-// flash_attention_backward_kernel.cu:47-246) for those shapes.  Design and measurements: DESIGN.md section 3.
+// flash_attention_backward_kernel.cu:47-246), one kernel for any N and d <= 128 there (dispatch :264-297).  Design and
+// measurements: DESIGN.md section 3.  The text below describes d = 128; the d = 64 differences are at the kernel template.
 //
 // Work split as fa2_bwd_dkdv_kernel (a workgroup owns 256 keys, dK^T / dV^T in 256 accumulator registers per wave), plus the
 // query gradient: the packed dS pairs each wave already forms for dK go to a [key][q] tile in LDS, and every wave
