@@ -127,6 +127,10 @@ KSCALED = os.environ.get("FA2_GEN_KSCALED", "0") == "1"
 # stage B): 24 instead of 31 ds_read_b128 in the stage whose reads alone fill the LDS array when all four waves are in it
 # (round 4, measured same-box with the dS tile's conflict-free key: 4.313 -> 4.280 ms; FA2_GEN_AILV=0 = the round-3 order)
 AILV = os.environ.get("FA2_GEN_AILV", "1") == "1"
+# stages C and D: the two key blocks of a d-tile in alternating order (kb 0, 1 | 1, 0 | 0, 1 ...), so that consecutive MFMAs
+# always share one operand -- the transposed fragment inside a pair, the packed P / dS fragment across two pairs (operand
+# switching is part of the energy of an MFMA: tools/probes/mfma_shape.hip modes 4-6)
+SNAKE = os.environ.get("FA2_GEN_SNAKE", "0") == "1"
 # ABLATIONS (timing only, WRONG RESULTS; var/ builds for tools/gpu_ab_multi.py): a comma-separated subset of
 #   noE (E's dS / K^T reads), noAK (A's K reads), noDMA (Q / dO / row-constant LDS-DMA), noDQ (running-sum loads and stores),
 #   noVALU (exp / mul / cvt), noDSW (dS tile writes), noRC (row-constant reads), noSEEN (progress prefetch)
@@ -200,6 +204,8 @@ def build(chain=False, masked=False):
         # stage to this body's dS packs (so E reads five MFMAs ahead instead of three).
         # (fragment slots are handed out in the order of use: the two stages interleave)
         xbusy = [gD - NS + 2 * DT - 2, gD - NS + 2 * DT - 1, gD - NS + 4 * DT - 2, gD - NS + 4 * DT - 1]      # last D-stage readers of dsf(0,0), (1,0), (0,1), (1,1)
+        if SNAKE and (DT - 1) % 2 == 1:            # the last d-tile of a half runs (kb 1, kb 0)
+            xbusy = [xbusy[1], xbusy[0], xbusy[3], xbusy[2]]
         for g, kind, s in sorted([(gBp(i), "B", i) for i in range(KS)] + [(gEs(i), "E", i) for i in range(NE)]):
             if kind == "B":
                 sg, fg = take(g + 1)
@@ -234,8 +240,9 @@ def build(chain=False, masked=False):
                         ka, kb_ = (nm, sp, dt, 0), (nm, sp, dt, 1)
                         rd(f"ds_read_b64_tr_b16 {slot_lo(sl)}, %[t{2 * dt}] offset:{basep}+{sp * 16 * ROWB}", ka, g, fr)
                         rd(f"ds_read_b64_tr_b16 {slot_hi(sl)}, %[t{2 * dt + 1}] offset:{basep}+{sp * 16 * ROWB}", kb_, g, fr)
-                        mfma[g] = (f"v_mfma_f32_32x32x16_bf16 {acc(0, dt)}, {slot(sl)}, {frag(0, sp)}, {acc(0, dt)}", [ka, kb_])
-                        mfma[g + 1] = (f"v_mfma_f32_32x32x16_bf16 {acc(1, dt)}, {slot(sl)}, {frag(1, sp)}, {acc(1, dt)}", [ka, kb_])
+                        k0, k1 = (1, 0) if (SNAKE and dt % 2 == 1) else (0, 1)
+                        mfma[g] = (f"v_mfma_f32_32x32x16_bf16 {acc(k0, dt)}, {slot(sl)}, {frag(k0, sp)}, {acc(k0, dt)}", [ka, kb_])
+                        mfma[g + 1] = (f"v_mfma_f32_32x32x16_bf16 {acc(k1, dt)}, {slot(sl)}, {frag(k1, sp)}, {acc(k1, dt)}", [ka, kb_])
         while ctr[0] % NSLOT:
             take(NS - 1)                          # skipped slot numbers: the rotation closes over a sub-tile
 
