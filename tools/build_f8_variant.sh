@@ -12,5 +12,5 @@ cp "$root"/cuda_flashattention_amd/csrc/*.h "$root"/cuda_flashattention_amd/csrc
 (cd "$root/tools" && env "${envs[@]}" python3 gen_fwd_fp8_body.py --out $tmp/fa2_fwd_fp8_body.inc >/dev/null)
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form -Wno-inline-asm -I"$root/include" "$@" -c $tmp/fa2_fwd_fp8.hip -o $tmp/fa2_fwd_fp8.o
 obj="$root/cuda_flashattention_amd/csrc/_obj"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$root/var/f8_$name.so" $(ls $obj/*.o | grep -v fa2_fwd_fp8.o | grep -v hooks) $tmp/fa2_fwd_fp8.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-Bsymbolic -o "$root/var/f8_$name.so" $(ls $obj/*.o | grep -v fa2_fwd_fp8.o | grep -v hooks) $tmp/fa2_fwd_fp8.o
 echo built var/f8_$name.so

@@ -163,9 +163,12 @@ def build(par, masked, dma, nomax=False):
             k += 1
             done = []
             for e, r in enumerate((4 * w, 4 * w + 1, 4 * w + 2, 4 * w + 3)):
-                f = valu(f"v_fma_f32 {sreg(op, blk, r)}, {sreg(op, blk, r)}, %[c2], -{MB}", "valu", rel, dl)
-                x = valu(f"v_exp_f32 {sreg(op, blk, r)}, {sreg(op, blk, r)}", "exp", rel, dl, after=[f])
-                valu(f"v_add_f32 {l(e & 1)}, {l(e & 1)}, {sreg(op, blk, r)}", "valu", rel, dl, after=[x])
+                # FA2_GEN_F8_ABL (timing only, wrong results): noFMA / expMOV / noADD -- what a class of the softmax's instructions costs
+                f = None if "noFMA" in ABL else valu(f"v_fma_f32 {sreg(op, blk, r)}, {sreg(op, blk, r)}, %[c2], -{MB}", "valu", rel, dl)
+                x = valu(f"{'v_mov_b32' if 'expMOV' in ABL else 'v_exp_f32'} {sreg(op, blk, r)}, {sreg(op, blk, r)}",
+                         "valu" if "expMOV" in ABL else "exp", rel, dl, after=[f] if f else None)
+                if "noADD" not in ABL:
+                    valu(f"v_add_f32 {l(e & 1)}, {l(e & 1)}, {sreg(op, blk, r)}", "valu", rel, dl, after=[x])
                 done.append(x)
             lo = valu(f"v_cvt_pk_fp8_f32 {pfw(op, blk, w)}, {sreg(op, blk, 4 * w)}, {sreg(op, blk, 4 * w + 1)}", "cvt", rel, dl, after=done[:2])
             valu(f"v_cvt_pk_fp8_f32 {pfw(op, blk, w)}, {sreg(op, blk, 4 * w + 2)}, {sreg(op, blk, 4 * w + 3)} op_sel:[0,0,1]", "cvt", rel, dl,
@@ -204,6 +207,9 @@ def build(par, masked, dma, nomax=False):
             text = f"s_add_u32 m0, %[mw], @NB+{which * NBUF * TILEB + i * WAVES * 1024}\n\t{pre or 's_nop 0'}\n\tbuffer_load_dwordx4 {dv}, {rs}, {so} offen lds"
             tasks.append(Task(text, COST["vmem"], g0, min(g0 + 2, NS - 1), "vmem", ("dma", which, i)))
     return mfma, tasks
+
+
+ABL = set(x for x in os.environ.get("FA2_GEN_F8_ABL", "").split(",") if x)
 
 
 def render(par, masked, dma, budget, nomax=False):
