@@ -46,7 +46,7 @@ READ_LATEST = int(os.environ.get("FA2_GEN_READ_LATEST", str(base.READ_LATEST)))
 V0 = 40
 KIMG = 0
 DSTILE = 256 * 64
-COST = dict(COST, ldsw=6, vmem=10, cmask=8)
+COST = dict(COST, ldsw=6, vmem=int(os.environ.get("FA2_GEN_COST_VMEM", "10")), cmask=8, lds=int(os.environ.get("FA2_GEN_COST_LDS", str(COST["lds"]))))
 
 
 def set_dim(d):
