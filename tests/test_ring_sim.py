@@ -198,6 +198,16 @@ def test_backward_every_policy(P, causal):
             assert np.linalg.norm(a - b) / np.linalg.norm(b) < 5e-3, (name, policy)
 
 
+@pytest.mark.parametrize("causal", [False, True], ids=["plain", "causal"])
+def test_backward_one_rank_writes_the_gradients_itself(causal):
+    """P = 1 (round 4): no shard to fetch, nothing to sum -- the schedule hands the caller's dQ / dK / dV straight to ONE
+    backward_block call with all three phases, instead of a piece buffer, fp32 sums and converts."""
+    got, ref = run_backward(1, 1, 2, 24, 32, causal, 0, rs.POLICIES[0])
+    for a, b, name in zip(got, ref, ("dQ", "dK", "dV")):
+        assert np.isfinite(a).all(), name
+        assert np.linalg.norm(a - b) / np.linalg.norm(b) < 5e-3, name
+
+
 def test_exchange_kv_is_a_ring_shift():
     """fa2_ring_exchange_kv (ring_exchange_kv, nccl_utils.h:133-142): every rank receives its predecessor's buffers."""
     lib = rs.ring_lib()
