@@ -288,6 +288,22 @@ def test_generated_bodies_pass_the_static_checker(inc):
         assert cb.check(cb.body(text, n), n) == []
 
 
+def test_lds_images_are_bank_conflict_free():
+    """tools/lds_bank_sim.py against the gfx950 bank rules: the swizzled [rows][D] tile image (row reads and transposed reads,
+    d = 128 and 64) and -- round 4 -- the single-kernel backward's dS tile (ds_write_b64 in four groups of 16 lanes against 32
+    banks, transposed reads in two groups of 32 against 64): no access pattern of the hot loops conflicts, the rounds 2-3 key of
+    the dS tile reproduces its two-way store conflict, and reads find what the writes stored."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("lds_bank_sim", os.path.join(ROOT, "tools", "lds_bank_sim.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    m.main()                                   # asserts inside
+    assert m.ds_tile(m.ds_key) == (1, 1) and m.ds_tile(m.ds_key_round3) == (2, 1)
+    # the key the kernel uses is the one the simulator checks
+    src = open(os.path.join(CSRC, "fa2_bwd_fused.hip")).read()
+    assert "#define FA2_FUSED_DSKEY(row) (((row) >> 1) & 7)" in src
+
+
 def test_generated_bodies_are_up_to_date(tmp_path):
     """The committed .inc files are what the generators produce (nobody edits them by hand, nobody forgets to regenerate)."""
     for gen, inc in (("gen_dkdv_body.py", "fa2_bwd_dkdv_body.inc"), ("gen_dq_body.py", "fa2_bwd_dq_body.inc"),
