@@ -208,6 +208,18 @@ def main():
                      "mean_shader_clock_mhz": round(mhz, 1),
                      "clock_source": "fa2_read_clocks before/after the window: per XCC d(s_memtime) / d(s_memrealtime) x 100 MHz, mean over the XCCs"}
 
+    # ---- what THIS device sustains on bare bf16 MFMAs with random operands (fa2_mfma_probe: every SIMD, nothing else): devices
+    # of one pool differ by several per cent on power-limited kernels, so the line carries the box's own ceiling beside the
+    # nominal peak.  After the timed region; ~0.2 s.
+    box = None
+    if rank == 0:
+        try:
+            tf, mhz = fa.ops.bare_mfma_tflops()
+            box = {"bare_mfma_tflops": round(tf, 1), "clock_mhz": round(mhz, 1),
+                   "what": "fa2_mfma_probe: back-to-back v_mfma_f32_32x32x16_bf16 on random operands, one wave per SIMD, ~0.15 s"}
+        except Exception as e:
+            box = {"error": repr(e)}
+
     flops_step = 14.0 * B * H * N * N * D
     ms_per_step = elapsed / args.steps * 1e3
     value = world * flops_step / (ms_per_step * 1e-3) / 1e12
@@ -230,6 +242,11 @@ def main():
                 "kernels_frac_algorithmic": {k: round(k_alg[k] / (k_ms[k] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) for k in k_alg},
                 "two_kernel_backward_ms": {k: round(v, 4) for k, v in two_kernel_ms.items()},
                 "whole_path_frac": round(value / world / PEAK_BF16_TFLOPS, 4)}
+    if box is not None:
+        roofline["this_device"] = box
+        if "bare_mfma_tflops" in box:
+            roofline["frac_of_this_device_bare_mfma"] = round(achieved / box["bare_mfma_tflops"], 4)
+            roofline["whole_path_frac_of_this_device_bare_mfma"] = round(value / world / box["bare_mfma_tflops"], 4)
 
     out = {
         "metric": "FA2 fwd+bwd TFLOP/s at (B=4,H=16,N=8192,d=128); % MFMA peak",

@@ -49,6 +49,7 @@ SIGNATURES = {
     "fa2_accumulate_bf16": (_i, [_vp, _vp, _sz, _i, _vp]),
     "fa2_accumulate_bf16_2d": (_i, [_vp, _vp, _sz, _sz, _sz, _i, _vp]),
     "fa2_read_clocks": (_i, [_vp, _vp]),
+    "fa2_mfma_probe": (_i, [_vp, _vp, _i, _i, _vp]),
     "fa2_fill_f32": (_i, [_vp, _sz, _f, _vp]),
     "fa2_convert_f32_to_bf16": (_i, [_vp, _vp, _sz, _vp]),
     "fa2_convert_bf16_to_f32": (_i, [_vp, _vp, _sz, _vp]),

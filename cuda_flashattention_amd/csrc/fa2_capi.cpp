@@ -542,6 +542,13 @@ int fa2_read_clocks(unsigned long long* out32, void* stream)
     return hip_status(fa2::launch_read_clocks(out32, (hipStream_t)stream));
 }
 
+int fa2_mfma_probe(const void* operands, float* out, int iters, int workgroups, void* stream)
+{
+    if (!operands || !out) return FA2_ERR_NULL_POINTER;
+    if (iters < 1 || workgroups < 1) return FA2_ERR_INVALID_SHAPE;
+    return hip_status(fa2::launch_mfma_probe(operands, out, iters, workgroups, (hipStream_t)stream));
+}
+
 int fa2_fill_f32(float* dst, size_t n, float value, void* stream)
 {
     if (!dst && n) return FA2_ERR_NULL_POINTER;

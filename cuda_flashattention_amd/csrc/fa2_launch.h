@@ -122,6 +122,7 @@ hipError_t launch_fa1_f32(const float* Q, const float* K, const float* V, float*
 
 // Element-wise helpers (fa2_util.hip).
 hipError_t launch_fill_f32(float* p, size_t n, float value, hipStream_t stream);
+hipError_t launch_mfma_probe(const void* in, float* out, int iters, int blocks, hipStream_t stream);
 hipError_t launch_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t stream);
 hipError_t launch_bf16_to_f32(const void* src, float* dst, size_t n, hipStream_t stream);
 hipError_t launch_read_clocks(unsigned long long* out, hipStream_t stream);

@@ -171,4 +171,30 @@ hipError_t launch_read_clocks(unsigned long long* out, hipStream_t stream)
     return hipGetLastError();
 }
 
+// Measurement aid: what THIS device sustains on nothing but v_mfma_f32_32x32x16_bf16 -- every SIMD, one wave each, four
+// independent accumulators, operands from `in` (the caller fills it with random bf16: the clock a device holds depends on the
+// operand data) -- so that a bench line can say how far the kernels are from the box they ran on, not only from the nominal
+// peak: devices of one pool differ by several per cent on power-limited kernels.  tools/probes/mfma_power.hip, mode 0.
+__global__ void __launch_bounds__(256) mfma_probe_kernel(const bf16x8* __restrict__ in, float* __restrict__ out, int iters)
+{
+    bf16x8 a0 = in[threadIdx.x], b0 = in[threadIdx.x + 256], a1 = in[threadIdx.x + 512], b1 = in[threadIdx.x + 768];
+    f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+    for (int i = 0; i < iters; ++i) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c0) : "v"(a0), "v"(b0));
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c1) : "v"(a1), "v"(b1));
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c2) : "v"(a0), "v"(b1));
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c3) : "v"(a1), "v"(b0));
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    float r = 0.0f;
+    for (int q = 0; q < 16; ++q) r += c0[q] + c1[q] + c2[q] + c3[q];
+    out[blockIdx.x * 256 + threadIdx.x] = r;
+}
+
+hipError_t launch_mfma_probe(const void* in, float* out, int iters, int blocks, hipStream_t stream)
+{
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16x8*)in, out, iters);
+    return hipGetLastError();
+}
+
 }  // namespace fa2

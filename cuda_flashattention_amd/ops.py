@@ -201,3 +201,34 @@ def mean_shader_clock_mhz(before, after):
     if not vals:
         raise RuntimeError("fa2_read_clocks: no XCC present in both samples")
     return sum(vals) / len(vals)
+
+
+def bare_mfma_tflops(seconds=0.15, workgroups=256):
+    """What this device sustains on nothing but bf16 MFMAs on random operands (fa2_mfma_probe): TFLOP/s over about `seconds`
+    of back-to-back launches after a ramp, and the mean shader clock it held.  A measurement aid for bench.py."""
+    lib = _capi.lib()
+    ops = (torch.rand(1024, 8, device="cuda") * 2 - 1).to(torch.bfloat16)
+    out = torch.empty(workgroups * 256, device="cuda")
+    s = _stream_ptr()
+    iters = 20000                                        # 4 x 20000 MFMAs per wave: ~1.4 ms per launch
+    run = lambda: check(lib.fa2_mfma_probe(ops.data_ptr(), out.data_ptr(), iters, workgroups, s), "fa2_mfma_probe")
+    for _ in range(30):                                  # ramp: the clock settles under load
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    c0 = read_clocks()
+    e0.record()
+    n = 0
+    while True:
+        for _ in range(10):
+            run()
+        n += 10
+        e1.record()
+        e1.synchronize()
+        if e0.elapsed_time(e1) >= seconds * 1e3:
+            break
+    c1 = read_clocks()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    flops = 4.0 * iters * workgroups * 4 * 32768.0 * n
+    return flops / ms / 1e9, mean_shader_clock_mhz(c0, c1)

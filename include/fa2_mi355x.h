@@ -261,6 +261,13 @@ int fa2_accumulate_bf16_2d(float* acc, const void* src, size_t rows, size_t cols
  * it held over the stretch (cuda_flashattention_amd.ops.mean_shader_clock_mhz averages the XCCs present in both). */
 int fa2_read_clocks(unsigned long long* out32, void* stream);
 
+/* Measurement aid: `workgroups` workgroups of four waves (one per SIMD) each run 4 x iters back-to-back
+ * v_mfma_f32_32x32x16_bf16 on the operands at `operands` (DEVICE memory, 1024 x 16 bytes of bf16 the caller fills -- random
+ * values: the clock a device holds depends on the data) and write workgroups x 256 floats to `out`.  4 x iters x workgroups x 4 x
+ * 32768 flops: timed by the caller with one workgroup per CU, it is what THIS device sustains on bare MFMAs -- the ceiling
+ * bench.py reports beside the nominal peak, because devices of one pool differ by several per cent on power-limited kernels. */
+int fa2_mfma_probe(const void* operands, float* out, int iters, int workgroups, void* stream);
+
 /* Element-wise helpers (grid-stride, HBM-bound). */
 int fa2_fill_f32(float* dst, size_t n, float value, void* stream);      /* init_array, cuda_helper.h:60-65 */
 int fa2_convert_f32_to_bf16(const float* src, void* dst, size_t n, void* stream);

@@ -223,3 +223,15 @@ def test_read_clocks_brackets_a_stretch_of_work():
     assert max(per) - min(per) < 0.25 * max(per), per       # eight clock domains, one power budget
     assert abs(fa.ops.mean_shader_clock_mhz(a, b) - sum(per) / 8) < 1e-6
     assert lib.fa2_read_clocks(None, s) == -1
+
+
+def test_bare_mfma_probe_reports_a_plausible_ceiling():
+    """fa2_mfma_probe (measurement aid): every SIMD on nothing but bf16 MFMAs with random operands; what bench.py reports as
+    this device's own ceiling.  Between the attention kernels' 1.2 - 1.4 PFLOP/s and the nominal 2.52."""
+    import cuda_flashattention_amd as fa
+    tf, mhz = fa.ops.bare_mfma_tflops(seconds=0.05)
+    assert 1300.0 < tf < 2520.0, tf
+    assert 1000.0 < mhz < 2600.0, mhz
+    assert abs(tf - mhz * 1e6 * 256 * 4 * 1024 / 1e12) / tf < 0.08      # back-to-back issue: 1024 flop per clock per SIMD
+    lib = fa._capi.lib()
+    assert lib.fa2_mfma_probe(None, None, 1, 1, None) == -1
