@@ -179,6 +179,7 @@ __global__ void __launch_bounds__(256) mfma_probe_kernel(const bf16x8* __restric
 {
     bf16x8 a0 = in[threadIdx.x], b0 = in[threadIdx.x + 256], a1 = in[threadIdx.x + 512], b1 = in[threadIdx.x + 768];
     f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+#pragma unroll 4
     for (int i = 0; i < iters; ++i) {
         asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c0) : "v"(a0), "v"(b0));
         asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c1) : "v"(a1), "v"(b1));

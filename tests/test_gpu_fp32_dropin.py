@@ -232,6 +232,6 @@ def test_bare_mfma_probe_reports_a_plausible_ceiling():
     tf, mhz = fa.ops.bare_mfma_tflops(seconds=0.05)
     assert 1300.0 < tf < 2520.0, tf
     assert 1000.0 < mhz < 2600.0, mhz
-    assert abs(tf - mhz * 1e6 * 256 * 4 * 1024 / 1e12) / tf < 0.08      # back-to-back issue: 1024 flop per clock per SIMD
+    assert 0.85 < tf / (mhz * 1e6 * 256 * 4 * 1024 / 1e12) <= 1.02      # (nearly) back-to-back issue: 1024 flop per clock per SIMD
     lib = fa._capi.lib()
     assert lib.fa2_mfma_probe(None, None, 1, 1, None) == -1
